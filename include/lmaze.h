@@ -1,0 +1,157 @@
+/*
+ * lmaze.h -- C ABI of the MI355X-native batched L-maze step path (liblmaze_hip.so).
+ *
+ * The reference (gkm2708/gym-lmaze) has no FFI: its hot path is the body of each env
+ * class's step()/reset() in pure Python.  This header is the boundary a maintainer of
+ * the reference would bind instead of those bodies (ctypes stub in INTEGRATION.md).
+ * Every entry point names the reference lines it replaces; "v0" below means
+ * gym_lmaze/envs/lmaze_env.py, "vK" means gym_lmaze/envs/lmaze_env_vK.py.
+ *
+ * Conventions
+ *   - plain pointers and sizes only; all pointers are DEVICE pointers (HBM) unless
+ *     the name ends in _host; the caller owns every buffer; nothing is allocated,
+ *     freed or synchronised inside; work is queued on `stream` (a hipStream_t passed
+ *     as void*, NULL = the null stream).
+ *   - N independent mazes ("envs"), struct-of-arrays, one element per env.
+ *   - a maze layout is G*G bytes, row-major, holding the reference's own cell
+ *     characters: 'W' wall, 'B' blank, 'S' start, 'X' goal marker (v0:37-48).
+ *   - coordinates: x = row (first array axis), y = column, exactly as in the reference.
+ *   - return value: 0 on success, a negative LMAZE_E_* for a rejected argument, or a
+ *     positive hipError_t from the launch.
+ */
+#ifndef LMAZE_H_
+#define LMAZE_H_
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define LMAZE_ABI_VERSION 1
+
+/* which reference class the transition rules come from */
+enum {
+    LMAZE_VARIANT_V0 = 0, /* LmazeEnv      (v0:146-237) 4-neighbour, sticky reward           */
+    LMAZE_VARIANT_V3 = 3  /* LmazeEnv_v3   (v3:220-402) 4-neighbour, look-ahead goal test    */
+};
+
+/* how `layout` is addressed */
+enum {
+    LMAZE_LAYOUT_SHARED = 0, /* one layout  uint8[G*G]    for every env (staged in LDS)      */
+    LMAZE_LAYOUT_PER_ENV = 1 /* own layout  uint8[N*G*G]  per env (LDS tile per workgroup)   */
+};
+
+/* compact observation: one int32 per cell; every reference plane is a bit test */
+enum {
+    LMAZE_OBS_BALL = 1, /* v0 plane 0 (v0:80,178-183)  | v3 plane 1 (v3:167,256-261)         */
+    LMAZE_OBS_WALL = 2, /* v0 plane 1 (v0:92-94): cell == 'W'                                */
+    LMAZE_OBS_GOAL = 4, /* v0 plane 2 (v0:96-98): cell == 'X' | v3 plane 2: one-hot goal_xy  */
+    LMAZE_OBS_FREE = 8  /* v0 plane 3 (v0:105-107): cell == 'B' | v3 plane 0: cell != 'W'    */
+};
+
+enum {
+    LMAZE_E_NULL = -1,      /* a required pointer is NULL                                     */
+    LMAZE_E_GRID = -2,      /* grid outside [3, LMAZE_MAX_GRID]                               */
+    LMAZE_E_VARIANT = -3,   /* params.variant does not match the entry point                  */
+    LMAZE_E_LAYOUT = -4,    /* unknown layout_mode                                            */
+    LMAZE_E_COUNT = -5,     /* n < 0 or n too large for one launch                            */
+    LMAZE_E_ALIGN = -6,     /* obs/ball_xy not aligned as documented                          */
+    LMAZE_E_EXPANSION = -7, /* expansion ratio / channel count out of range                   */
+    LMAZE_E_NODEVICE = -8   /* no HIP device / wrong architecture                             */
+};
+
+#define LMAZE_MAX_GRID 64
+#define LMAZE_MAX_CHANNELS 8
+
+/* Constants the reference hard-codes in __init__ (v0:17-23, v3:76-99). */
+typedef struct LmazeParams {
+    int32_t variant;     /* LMAZE_VARIANT_*                                                  */
+    int32_t grid;        /* G = realgrid, side of the square layout incl. border (v0:17)     */
+    int32_t layout_mode; /* LMAZE_LAYOUT_*                                                   */
+    int32_t step_limit;  /* v0: done when stepCount == limit (v0:247); v3: > limit (v3:398)  */
+    float reward_wall;   /* negativeNominal  -1.0   (v0:21)                                  */
+    float reward_move;   /* positiveNominal  -0.01  (v0:22)                                  */
+    float reward_goal;   /* positiveFull    100.0   (v0:23)                                  */
+    int32_t reserved;    /* must be 0                                                        */
+} LmazeParams;
+
+int lmaze_abi_version(void);
+
+/* Human-readable text for a code returned by any entry point (static storage). */
+const char* lmaze_strerror(int code);
+
+/* Number of visible HIP devices and, for `device`, CU count / arch name ("gfx950").
+ * Returns 0 or LMAZE_E_NODEVICE.  name_host may be NULL. */
+int lmaze_device_info(int device, int32_t* cu_count_host, char* name_host, int32_t name_len);
+
+/*
+ * One step() of N v0 mazes: replaces v0:146-237 (action decode 153-170, collision and
+ * position update 172-195, reward 174/184/194, done 246-249, plane build 208-215).
+ *   action      int32[N]    0:(-1,0) 1:(+1,0) 2:(0,-1) 3:(0,+1), anything else (0,0)
+ *   ball_xy     int32[N,2]  (ball_x0, ball_y0), read and updated; 8-byte aligned
+ *   step_count  int32[N]    stepCount, incremented first (v0:151)
+ *   reward      float[N]    read AND written: v0 keeps the previous reward when the
+ *                           target cell is neither 'W','B' nor 'X' (no else, v0:172-195)
+ *   done        uint8[N]    reward == reward_goal || step_count == step_limit (v0:246-249)
+ *   goal_count  int32[N]    goalCount (v0:195); may be NULL
+ *   obs         int32[N,G,G] compact planes after the move, fully rewritten; may be NULL
+ *                           (transition only); 16-byte aligned
+ * Envs never auto-reset (the reference does not); stepping after done follows v0 exactly.
+ */
+int lmaze_step_v0(const LmazeParams* params, const uint8_t* layout, const int32_t* action,
+                  int32_t* ball_xy, int32_t* step_count, float* reward, uint8_t* done,
+                  int32_t* goal_count, int32_t* obs, int64_t n, void* stream);
+
+/*
+ * One step() of N v3 mazes: replaces v3:220-402 (decode 234-247, collision/move 251-262,
+ * look-ahead goal test 264-265, done 398).  The caller maps the reference's string
+ * actions to ids ("left"/"0"->0, "right"/"1"->1, "up"/"2"->2, "down"/"3"->3, anything
+ * else, including a Python int, -> a no-op id such as -1).
+ *   goal_xy     int32[N,2]  (goal_x, goal_y), read only (set by reset, v3:147-152)
+ *   reward      float[N]    written only (re-zeroed to -0.0 every step, v3:224)
+ *   done        uint8[N]    reward == reward_goal || step_count > step_limit
+ */
+int lmaze_step_v3(const LmazeParams* params, const uint8_t* layout, const int32_t* action,
+                  int32_t* ball_xy, const int32_t* goal_xy, int32_t* step_count, float* reward,
+                  uint8_t* done, int32_t* obs, int64_t n, void* stream);
+
+/*
+ * Compact planes of the CURRENT state without stepping: what reset() returns after
+ * placement (v0:92-120, v3:166-196).  goal_xy is read for LMAZE_VARIANT_V3 only (NULL
+ * otherwise).
+ */
+int lmaze_observe(const LmazeParams* params, const uint8_t* layout, const int32_t* ball_xy,
+                  const int32_t* goal_xy, int32_t* obs, int64_t n, void* stream);
+
+/*
+ * Masked on-device reset: replaces the placement + bookkeeping part of reset()
+ * (v0:67-110; v3:142-167).  For every env with mask[i] != 0 (mask NULL = all):
+ * step_count = 0, reward = -0.0, done = 0, and a new ball cell (v3: first a new goal
+ * cell) drawn uniformly from the cells the reference's rejection loop accepts
+ * (v0:70-78: interior, not 'W', not 'X'; v3:147-161: goal interior not 'W', ball interior
+ * not 'W' and != goal).  Draws come from Philox4x32-10 keyed by (seed, env index,
+ * epoch); the reference draws from Python's global Mersenne Twister, so placement
+ * parity with it is distributional, not bitwise.  obs (nullable) gets the reset planes.
+ */
+int lmaze_reset(const LmazeParams* params, const uint8_t* layout, const uint8_t* mask,
+                uint64_t seed, uint64_t epoch, int32_t* ball_xy, int32_t* goal_xy,
+                int32_t* step_count, float* reward, uint8_t* done, int32_t* obs, int64_t n,
+                void* stream);
+
+/*
+ * Reference-layout observation: replaces the 5-deep upsample loop (v0:217-234,
+ * v3:295-301).  out[i, c, x*E+xx, y*E+yy] = float((obs[i,x,y] & channel_mask[c]) != 0).
+ *   obs           int32[N,G,G]        compact planes
+ *   channel_mask  int32[channels]     HOST array, one LMAZE_OBS_* bit per output plane,
+ *                                     e.g. v0 {1,2,4,8}, v3 {8,1,4}
+ *   out           float[N,channels,G*E,G*E], 16-byte aligned
+ */
+int lmaze_render_expanded(const int32_t* obs, int32_t grid, int32_t expansion,
+                          const int32_t* channel_mask_host, int32_t channels, float* out,
+                          int64_t n, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* LMAZE_H_ */

@@ -1,0 +1,76 @@
+"""CPU: the C oracle (oracle/lmaze_oracle.c) replays every golden fixture bit-exactly.
+
+The fixtures were produced by the reference's own step()/reset() (oracle/gen_golden.py);
+this is what pins the oracle ("parity pinned" in its header)."""
+import numpy as np
+import pytest
+
+import oracle_lib as O
+from conftest import golden_files
+from helpers import (V0_CHANNEL_MASK, V3_CHANNEL_MASK, compact_to_ref_bits, f32_bits, load_golden,
+                     obs_hash, ref_reward_bits)
+
+
+def _replay(g, variant):
+    G = g["layout"].shape[0]
+    E = int(g["E"])
+    T = len(g["actions"])
+    layout = np.ascontiguousarray(g["layout"])
+    v3 = variant == O.VARIANT_V3
+    p = O.params(variant, G)
+    cmask = V3_CHANNEL_MASK if v3 else V0_CHANNEL_MASK
+    ball = np.zeros((1, 2), np.int32)
+    goal = np.zeros((1, 2), np.int32)
+    sc = np.zeros(1, np.int32)
+    rew = np.zeros(1, np.float32)
+    done = np.zeros(1, np.uint8)
+    gc = np.zeros(1, np.int32)
+    obs = np.zeros((1, G, G), np.int32)
+    n_reset = 0
+    for t in range(T):
+        if g["reset_before"][t]:
+            # inject the reference's own placement (its RNG stream is not reproduced on device)
+            ball[0] = g["ball_before"][t]
+            if v3:
+                goal[0] = g["goal_before"][t]
+            sc[0] = 0
+            rew[0] = -0.0
+            O.observe(p, layout, ball, goal if v3 else None, obs)
+            assert (compact_to_ref_bits(obs[0], cmask) == g["reset_planes"][n_reset]).all()
+            full = O.render_expanded(obs, G, E, cmask)
+            assert obs_hash(full[0]) == g["reset_hash"][n_reset]
+            n_reset += 1
+        assert tuple(ball[0]) == tuple(g["ball_before"][t])
+        a = g["actions"][t:t + 1].copy()
+        if v3:
+            O.step_v3(p, layout, a, ball, goal, sc, rew, done, obs)
+        else:
+            O.step_v0(p, layout, a, ball, sc, rew, done, gc, obs)
+        assert f32_bits(rew)[0] == ref_reward_bits(g["reward"][t]), (t, rew[0], g["reward"][t])
+        assert done[0] == g["done"][t], t
+        assert tuple(ball[0]) == tuple(g["ball"][t]), t
+        assert sc[0] == g["step_count"][t], t
+        if not v3:
+            assert gc[0] == g["goal_count"][t], t
+        assert (compact_to_ref_bits(obs[0], cmask) == g["planes"][t]).all(), t
+        full = O.render_expanded(obs, G, E, cmask)
+        assert obs_hash(full[0]) == g["obs_hash"][t], t
+    assert n_reset == len(g["reset_hash"])
+
+
+@pytest.mark.parametrize("name", golden_files("v0_"))
+def test_oracle_v0_matches_reference(name):
+    _replay(load_golden(name), O.VARIANT_V0)
+
+
+@pytest.mark.parametrize("name", golden_files("v3_"))
+def test_oracle_v3_matches_reference(name):
+    _replay(load_golden(name), O.VARIANT_V3)
+
+
+def test_philox_known_answers():
+    # Random123 kat_vectors, philox4x32 10 rounds
+    assert O.philox4x32_10([0, 0, 0, 0], [0, 0]) == [0x6627e8d5, 0xe169c58d, 0xbc57ac4c, 0x9b00dbd8]
+    assert O.philox4x32_10([0xffffffff] * 4, [0xffffffff] * 2) == [0x408f276d, 0x41c83b0e, 0xa20bc7c6, 0x6d5451fd]
+    assert O.philox4x32_10([0x243f6a88, 0x85a308d3, 0x13198a2e, 0x03707344],
+                           [0xa4093822, 0x299f31d0]) == [0xd16cfe09, 0x94fdcceb, 0x5001e420, 0x24126ea1]
