@@ -1,0 +1,184 @@
+#!/usr/bin/env python3
+"""bench.py -- env-steps/s of the batched L-maze step path on N MI355X of one node.
+
+Workload (BASELINE.json configs[2]): 1 048 576 parallel 11x11 mazes per
+GPU, v0 transition rules, shared open-room layout, compact int32 observation fully
+re-rendered every step, uniform random actions pre-generated on the device.  A "step" is one
+lmaze_step_v0 launch over the whole per-GPU batch.  With --gpus N every rank owns its own
+1 048 576 envs (weak scaling, configs[3] at N=8); envs are independent, so there is no
+collective on the step path -- torch.distributed is used only for the start/stop barrier
+and the max-over-ranks time.
+
+One JSON line on rank 0; see README/DESIGN.md for the fields.
+"""
+import argparse
+import importlib
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (guides/MI355X_MICROARCH.md)
+
+
+def bytes_per_env_step(G, per_env_layout=False):
+    """reads action 4 + ball 8 + stepCount 4 + reward 4; writes ball 8 + stepCount 4
+    + reward 4 + done 1; obs write 4*G*G; + G*G layout bytes when every env has its own maze."""
+    return 37 + 4 * G * G + (G * G if per_env_layout else 0)
+
+
+def cpu_baseline(G, layout_codes, budget_s=12.0):
+    """The C oracle (a port, not the reference interpreter) on this box's host cores, on a
+    bounded sample of the same workload."""
+    import numpy as np
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import oracle_lib as O
+    N = 1 << 18
+    rs = np.random.RandomState(1)
+    p = O.params(O.VARIANT_V0, G, O.LAYOUT_SHARED)
+    ok = np.argwhere((layout_codes != ord("W")) & (layout_codes != ord("X")))
+    ball = np.ascontiguousarray(ok[rs.randint(len(ok), size=N)].astype(np.int32))
+    sc = np.zeros(N, np.int32)
+    rew = np.zeros(N, np.float32)
+    done = np.zeros(N, np.uint8)
+    gc = np.zeros(N, np.int32)
+    obs = np.zeros((N, G, G), np.int32)
+    acts = [rs.randint(0, 4, N).astype(np.int32) for _ in range(8)]
+    lay = np.ascontiguousarray(layout_codes)
+    O.step_v0(p, lay, acts[0], ball, sc, rew, done, gc, obs)   # warm-up / page-in
+    t0 = time.perf_counter()
+    O.step_v0(p, lay, acts[1], ball, sc, rew, done, gc, obs)
+    one = max(time.perf_counter() - t0, 1e-6)
+    steps = int(max(4, min(2000, budget_s / one)))
+    t0 = time.perf_counter()
+    for t in range(steps):
+        O.step_v0(p, lay, acts[t & 7], ball, sc, rew, done, gc, obs)
+    dt = time.perf_counter() - t0
+    return {"value": N * steps / dt, "unit": "env-steps/s", "cores": O.threads(), "kind": "port",
+            "sample": "%d envs x %d steps of the same 11x11 v0 workload, C oracle (OpenMP), %.1f s" % (N, steps, dt)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=300)
+    ap.add_argument("--warmup", type=int, default=30)
+    ap.add_argument("--envs", type=int, default=1 << 20, help="envs per GPU")
+    ap.add_argument("--grid", type=int, default=11)
+    ap.add_argument("--per-env-layouts", action="store_true", help="configs[4]-style: own random maze per env")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--action-rows", type=int, default=32, help="distinct pre-generated action rows (ring)")
+    args = ap.parse_args()
+
+    import numpy as np
+    import torch
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch with: python -m torch.distributed.run --nproc-per-node %d bench.py --gpus %d"
+                             % (args.gpus, args.gpus))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: the HIP kernels are the only step path")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+
+    pkg = importlib.import_module("gym-lmaze_amd")
+    G, N = args.grid, args.envs
+    env_base = rank * N
+    layout = pkg.layouts.to_codes(pkg.layouts.open_room(G, (G // 2, G // 2)))
+    if args.per_env_layouts:
+        gen = torch.Generator(device=dev).manual_seed(7 + rank)
+        lay = torch.where(torch.rand((N, G, G), device=dev, generator=gen) < 0.25, ord("W"), ord("B")).to(torch.uint8)
+        lay[:, 0, :] = ord("W"); lay[:, -1, :] = ord("W"); lay[:, :, 0] = ord("W"); lay[:, :, -1] = ord("W")
+        lay[:, 1, 1] = ord("S")
+        lay[:, G - 2, G - 2] = ord("X")
+        env = pkg.LmazeVecEnv(N, variant="v0", per_env_layouts=lay, device=dev, seed=1, env_base=env_base)
+        workload = "%d x %dx%d mazes per GPU, v0 rules, per-env random layouts (p_wall 0.25), compact int32 obs" % (N, G, G)
+    else:
+        env = pkg.LmazeVecEnv(N, variant="v0", layout=layout, device=dev, seed=1, env_base=env_base)
+        workload = "%d x %dx%d mazes per GPU, v0 rules, shared open-room layout, compact int32 obs" % (N, G, G)
+
+    gen = torch.Generator(device=dev).manual_seed(1 + rank)      # torch's device generator is Philox
+    R = args.action_rows
+    actions = torch.randint(0, 4, (R, N), dtype=torch.int32, device=dev, generator=gen)
+    row_ptr = [actions[r].data_ptr() for r in range(R)]
+
+    def run(k0, k):
+        for t in range(k0, k0 + k):
+            env.step_raw(row_ptr[t % R])
+
+    with torch.cuda.device(dev):
+        run(0, args.warmup)
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+        ev = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
+        t0 = time.perf_counter()
+        ev[0].record()
+        for t in range(args.steps):
+            env.step_raw(row_ptr[(args.warmup + t) % R])
+            ev[t + 1].record()
+        torch.cuda.synchronize()
+        elapsed = time.perf_counter() - t0
+        if dist is not None:
+            dist.barrier()
+            tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            elapsed = float(tt.item())
+    # per-launch GPU time from HIP events recorded on the launch stream
+    per = np.array([ev[i].elapsed_time(ev[i + 1]) for i in range(args.steps)])  # ms
+    kern_ms = float(ev[0].elapsed_time(ev[-1]) / args.steps)
+
+    # sanity: the run really stepped (every env advanced warmup+steps times)
+    assert int(env.step_count.min().item()) == args.warmup + args.steps
+
+    if rank == 0:
+        B = bytes_per_env_step(G, args.per_env_layouts)
+        total_steps = world * N * args.steps
+        value = total_steps / elapsed
+        achieved = N * B / (kern_ms * 1e-3) / 1e9
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "traffic.json")
+        if os.path.exists(tpath):
+            try:
+                tj = json.load(open(tpath))
+                key = "g%d_%s" % (G, "perenv" if args.per_env_layouts else "shared")
+                traffic = tj.get(key, {}).get("hbm_bytes_per_launch")
+            except Exception:
+                traffic = None
+        out = {
+            "metric": "env steps/sec (whole node), 1M parallel 11x11 mazes at 1/2/4/8 MI355X",
+            "value": value, "unit": "env-steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "int32", "data": "synthetic",
+            "config": {"workload": workload, "envs_per_gpu": N, "grid": G, "global_envs": world * N,
+                       "parallelism": "independent env shards, no collective on the step path",
+                       "actions": "uniform{0..3} int32[%d,N] ring, torch Philox seed 1+rank" % R},
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                         "kernel": "lmaze::step_%s_kernel<%d, v0>" % ("perenv" if args.per_env_layouts else "shared", G),
+                         "bytes_per_env_step": B, "kernel_ms_avg": kern_ms,
+                         "kernel_ms_median": float(np.median(per)), "kernel_ms_min": float(per.min())},
+        }
+        if not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(G, layout)
+        print(json.dumps(out))
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

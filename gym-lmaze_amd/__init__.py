@@ -1,0 +1,19 @@
+"""gym-lmaze_amd: MI355X-native batched L-maze step path (drop-in for gkm2708/gym-lmaze).
+
+The directory name carries a hyphen, so import it with
+    importlib.import_module("gym-lmaze_amd")
+or, as a user of the reference would, through the alias package `gym_lmaze`
+(`import gym_lmaze; gym_lmaze.make("lmaze-v0")`, `from gym_lmaze.envs import LmazeEnv`).
+
+Importing this package loads liblmaze_hip.so and raises if it is missing: the HIP kernels
+are the only implementation of the step path.
+"""
+from . import _abi  # noqa: F401  (fails loudly when the HIP library is absent)
+from . import layouts  # noqa: F401
+from .compat import make, register, registered_ids  # noqa: F401
+from .envs import LmazeEnv, LmazeEnv_v3  # noqa: F401
+from .sharding import shard_range  # noqa: F401
+from .vec_env import VARIANTS, LmazeVecEnv  # noqa: F401
+
+__all__ = ["LmazeVecEnv", "LmazeEnv", "LmazeEnv_v3", "VARIANTS", "layouts", "make", "register",
+           "registered_ids", "shard_range"]

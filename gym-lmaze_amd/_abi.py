@@ -1,0 +1,88 @@
+"""ctypes binding of liblmaze_hip.so -- the C ABI declared in include/lmaze.h.
+
+This is the only way the package reaches the kernels, and there is no other compute path:
+if the library is missing or does not load, importing this module raises.  Build it with
+`python -c "import __graft_entry__ as g; g.build()"` or `make -C gym-lmaze_amd/csrc`.
+"""
+import ctypes as C
+import os
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "liblmaze_hip.so")
+
+ABI_VERSION = 1
+VARIANT_V0, VARIANT_V3 = 0, 3
+LAYOUT_SHARED, LAYOUT_PER_ENV = 0, 1
+OBS_BALL, OBS_WALL, OBS_GOAL, OBS_FREE = 1, 2, 4, 8
+MAX_GRID, MAX_CHANNELS = 64, 8
+
+# every symbol include/lmaze.h declares (tests/test_abi_symbols.py parses the header and
+# checks this list and the loaded library against it)
+SYMBOLS = ("lmaze_abi_version", "lmaze_strerror", "lmaze_device_info", "lmaze_step_v0", "lmaze_step_v3",
+           "lmaze_observe", "lmaze_reset", "lmaze_render_expanded")
+
+
+class LmazeParams(C.Structure):
+    """struct LmazeParams of include/lmaze.h (constants the reference hard-codes in __init__)."""
+    _fields_ = [("variant", C.c_int32), ("grid", C.c_int32), ("layout_mode", C.c_int32),
+                ("step_limit", C.c_int32), ("reward_wall", C.c_float), ("reward_move", C.c_float),
+                ("reward_goal", C.c_float), ("reserved", C.c_int32)]
+
+
+class LmazeError(RuntimeError):
+    def __init__(self, fn, code):
+        self.code = code
+        RuntimeError.__init__(self, "%s failed: %d (%s)" % (fn, code, strerror(code)))
+
+
+def _load():
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            "gym-lmaze_amd: %s is missing. The HIP library is the only compute path (no CPU fallback); "
+            "build it with `make -C %s` (hipcc, --offload-arch=gfx950)." % (LIB_PATH, os.path.join(HERE, "csrc")))
+    lib = C.CDLL(LIB_PATH)
+    vp, i32, i64, u64 = C.c_void_p, C.c_int32, C.c_int64, C.c_uint64
+    P = C.POINTER(LmazeParams)
+    lib.lmaze_abi_version.restype = C.c_int
+    lib.lmaze_abi_version.argtypes = []
+    lib.lmaze_strerror.restype = C.c_char_p
+    lib.lmaze_strerror.argtypes = [C.c_int]
+    lib.lmaze_device_info.restype = C.c_int
+    lib.lmaze_device_info.argtypes = [C.c_int, C.POINTER(i32), C.c_char_p, i32]
+    lib.lmaze_step_v0.restype = C.c_int
+    lib.lmaze_step_v0.argtypes = [P, vp, vp, vp, vp, vp, vp, vp, vp, i64, vp]
+    lib.lmaze_step_v3.restype = C.c_int
+    lib.lmaze_step_v3.argtypes = [P, vp, vp, vp, vp, vp, vp, vp, vp, i64, vp]
+    lib.lmaze_observe.restype = C.c_int
+    lib.lmaze_observe.argtypes = [P, vp, vp, vp, vp, i64, vp]
+    lib.lmaze_reset.restype = C.c_int
+    lib.lmaze_reset.argtypes = [P, vp, vp, u64, u64, i64, vp, vp, vp, vp, vp, vp, i64, vp]
+    lib.lmaze_render_expanded.restype = C.c_int
+    lib.lmaze_render_expanded.argtypes = [vp, i32, i32, C.POINTER(i32), i32, vp, i64, vp]
+    if lib.lmaze_abi_version() != ABI_VERSION:
+        raise ImportError("liblmaze_hip.so ABI %d != binding %d: rebuild" % (lib.lmaze_abi_version(), ABI_VERSION))
+    return lib
+
+
+lib = _load()
+
+
+def strerror(code):
+    return lib.lmaze_strerror(int(code)).decode("ascii", "replace")
+
+
+def check(fn, code):
+    if code != 0:
+        raise LmazeError(fn, code)
+
+
+def device_info(device=0):
+    cu = C.c_int32(0)
+    name = C.create_string_buffer(64)
+    check("lmaze_device_info", lib.lmaze_device_info(int(device), C.byref(cu), name, 64))
+    return {"cu_count": cu.value, "arch": name.value.decode("ascii", "replace")}
+
+
+def make_params(variant, grid, layout_mode, step_limit, reward_wall, reward_move, reward_goal):
+    return LmazeParams(int(variant), int(grid), int(layout_mode), int(step_limit), float(reward_wall),
+                       float(reward_move), float(reward_goal), 0)

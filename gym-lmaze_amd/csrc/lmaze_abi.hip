@@ -1,0 +1,165 @@
+// lmaze_abi.hip -- the extern "C" surface declared in include/lmaze.h: argument checks and
+// launches only.  No allocation, no synchronisation, no host-side compute fallback: if the
+// launch fails the hipError_t goes back to the caller.
+#include <string.h>
+
+#include "lmaze_common.h"
+
+
+using namespace lmaze;
+
+static int check_params(const LmazeParams* p, int64_t n) {
+    if (!p) return LMAZE_E_NULL;
+    if (p->grid < 3 || p->grid > LMAZE_MAX_GRID) return LMAZE_E_GRID;
+    if (p->layout_mode != LMAZE_LAYOUT_SHARED && p->layout_mode != LMAZE_LAYOUT_PER_ENV) return LMAZE_E_LAYOUT;
+    if (n < 0 || n > ((int64_t)1 << 40)) return LMAZE_E_COUNT;
+    return 0;
+}
+
+static bool misaligned(const void* p, uintptr_t a) { return ((uintptr_t)p & (a - 1)) != 0; }
+
+static StepArgs make_args(const LmazeParams* p, const uint8_t* layout, const int32_t* action, int32_t* ball_xy,
+                          const int32_t* goal_xy, int32_t* step_count, float* reward, uint8_t* done,
+                          int32_t* goal_count, int32_t* obs, int64_t n) {
+    StepArgs a;
+    a.layout = layout;
+    a.action = action;
+    a.ball = reinterpret_cast<int2*>(ball_xy);
+    a.goal = reinterpret_cast<const int2*>(goal_xy);
+    a.step_count = step_count;
+    a.reward = reward;
+    a.done = done;
+    a.goal_count = goal_count;
+    a.obs = obs;
+    a.n = n;
+    a.grid = p->grid;
+    a.step_limit = p->step_limit;
+    a.reward_wall = p->reward_wall;
+    a.reward_move = p->reward_move;
+    a.reward_goal = p->reward_goal;
+    a.envs_per_block = 0;
+    return a;
+}
+
+extern "C" {
+
+int lmaze_abi_version(void) { return LMAZE_ABI_VERSION; }
+
+const char* lmaze_strerror(int code) {
+    switch (code) {
+        case 0: return "ok";
+        case LMAZE_E_NULL: return "a required pointer is NULL";
+        case LMAZE_E_GRID: return "grid outside [3, 64]";
+        case LMAZE_E_VARIANT: return "params.variant does not match the entry point";
+        case LMAZE_E_LAYOUT: return "unknown layout_mode";
+        case LMAZE_E_COUNT: return "env count out of range";
+        case LMAZE_E_ALIGN: return "buffer not aligned as documented";
+        case LMAZE_E_EXPANSION: return "expansion ratio / channel count out of range";
+        case LMAZE_E_NODEVICE: return "no usable HIP device";
+        default: return code > 0 ? hipGetErrorString((hipError_t)code) : "unknown lmaze error";
+    }
+}
+
+int lmaze_device_info(int device, int32_t* cu_count_host, char* name_host, int32_t name_len) {
+    int count = 0;
+    if (hipGetDeviceCount(&count) != hipSuccess || count <= 0 || device < 0 || device >= count) {
+        (void)hipGetLastError();
+        return LMAZE_E_NODEVICE;
+    }
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device) != hipSuccess) return LMAZE_E_NODEVICE;
+    if (cu_count_host) *cu_count_host = prop.multiProcessorCount;
+    if (name_host && name_len > 0) {
+        strncpy(name_host, prop.gcnArchName, (size_t)name_len - 1);
+        name_host[name_len - 1] = 0;
+    }
+    return 0;
+}
+
+int lmaze_step_v0(const LmazeParams* params, const uint8_t* layout, const int32_t* action, int32_t* ball_xy,
+                  int32_t* step_count, float* reward, uint8_t* done, int32_t* goal_count, int32_t* obs,
+                  int64_t n, void* stream) {
+    int rc = check_params(params, n);
+    if (rc) return rc;
+    if (params->variant != LMAZE_VARIANT_V0) return LMAZE_E_VARIANT;
+    if (!layout || !action || !ball_xy || !step_count || !reward || !done) return LMAZE_E_NULL;
+    if (misaligned(ball_xy, 8) || misaligned(obs, 16) || misaligned(layout, 16)) return LMAZE_E_ALIGN;
+    StepArgs a = make_args(params, layout, action, ball_xy, nullptr, step_count, reward, done, goal_count, obs, n);
+    return (int)launch_step(LMAZE_VARIANT_V0, true, a, params->layout_mode, (hipStream_t)stream);
+}
+
+int lmaze_step_v3(const LmazeParams* params, const uint8_t* layout, const int32_t* action, int32_t* ball_xy,
+                  const int32_t* goal_xy, int32_t* step_count, float* reward, uint8_t* done, int32_t* obs,
+                  int64_t n, void* stream) {
+    int rc = check_params(params, n);
+    if (rc) return rc;
+    if (params->variant != LMAZE_VARIANT_V3) return LMAZE_E_VARIANT;
+    if (!layout || !action || !ball_xy || !goal_xy || !step_count || !reward || !done) return LMAZE_E_NULL;
+    if (misaligned(ball_xy, 8) || misaligned(goal_xy, 8) || misaligned(obs, 16) || misaligned(layout, 16))
+        return LMAZE_E_ALIGN;
+    StepArgs a = make_args(params, layout, action, ball_xy, goal_xy, step_count, reward, done, nullptr, obs, n);
+    return (int)launch_step(LMAZE_VARIANT_V3, true, a, params->layout_mode, (hipStream_t)stream);
+}
+
+int lmaze_observe(const LmazeParams* params, const uint8_t* layout, const int32_t* ball_xy,
+                  const int32_t* goal_xy, int32_t* obs, int64_t n, void* stream) {
+    int rc = check_params(params, n);
+    if (rc) return rc;
+    if (params->variant != LMAZE_VARIANT_V0 && params->variant != LMAZE_VARIANT_V3) return LMAZE_E_VARIANT;
+    if (!layout || !ball_xy || !obs) return LMAZE_E_NULL;
+    if (params->variant == LMAZE_VARIANT_V3 && !goal_xy) return LMAZE_E_NULL;
+    if (misaligned(ball_xy, 8) || misaligned(goal_xy, 8) || misaligned(obs, 16) || misaligned(layout, 16))
+        return LMAZE_E_ALIGN;
+    StepArgs a = make_args(params, layout, nullptr, const_cast<int32_t*>(ball_xy), goal_xy, nullptr, nullptr,
+                           nullptr, nullptr, obs, n);
+    return (int)launch_step(params->variant, false, a, params->layout_mode, (hipStream_t)stream);
+}
+
+int lmaze_reset(const LmazeParams* params, const uint8_t* layout, const uint8_t* mask, uint64_t seed,
+                uint64_t epoch, int64_t env_base, int32_t* ball_xy, int32_t* goal_xy, int32_t* step_count, float* reward,
+                uint8_t* done, int32_t* obs, int64_t n, void* stream) {
+    int rc = check_params(params, n);
+    if (rc) return rc;
+    if (params->variant != LMAZE_VARIANT_V0 && params->variant != LMAZE_VARIANT_V3) return LMAZE_E_VARIANT;
+    if (!layout || !ball_xy || !step_count || !reward || !done) return LMAZE_E_NULL;
+    if (params->variant == LMAZE_VARIANT_V3 && !goal_xy) return LMAZE_E_NULL;
+    if (misaligned(ball_xy, 8) || misaligned(goal_xy, 8) || misaligned(obs, 16) || misaligned(layout, 16))
+        return LMAZE_E_ALIGN;
+    ResetArgs r;
+    r.layout = layout;
+    r.mask = mask;
+    r.ball = reinterpret_cast<int2*>(ball_xy);
+    r.goal = reinterpret_cast<int2*>(goal_xy);
+    r.step_count = step_count;
+    r.reward = reward;
+    r.done = done;
+    r.n = n;
+    r.seed = seed;
+    r.epoch = epoch;
+    r.env_base = env_base;
+    r.grid = params->grid;
+    hipError_t e = launch_reset(params->variant, r, params->layout_mode, (hipStream_t)stream);
+    if (e != hipSuccess || !obs) return (int)e;
+    StepArgs a = make_args(params, layout, nullptr, ball_xy, goal_xy, nullptr, nullptr, nullptr, nullptr, obs, n);
+    return (int)launch_step(params->variant, false, a, params->layout_mode, (hipStream_t)stream);
+}
+
+int lmaze_render_expanded(const int32_t* obs, int32_t grid, int32_t expansion, const int32_t* channel_mask_host,
+                          int32_t channels, float* out, int64_t n, void* stream) {
+    if (!obs || !channel_mask_host || !out) return LMAZE_E_NULL;
+    if (grid < 1 || grid > LMAZE_MAX_GRID) return LMAZE_E_GRID;
+    if (expansion < 1 || expansion > 16 || channels < 1 || channels > LMAZE_MAX_CHANNELS) return LMAZE_E_EXPANSION;
+    if (n < 0 || n > ((int64_t)1 << 40)) return LMAZE_E_COUNT;
+    if (misaligned(out, 16) || misaligned(obs, 4)) return LMAZE_E_ALIGN;
+    ExpandArgs a;
+    a.obs = obs;
+    a.out = out;
+    a.n = n;
+    a.grid = grid;
+    a.expansion = expansion;
+    a.channels = channels;
+    for (int c = 0; c < LMAZE_MAX_CHANNELS; ++c) a.mask[c] = c < channels ? channel_mask_host[c] : 0;
+    return (int)launch_expand(a, (hipStream_t)stream);
+}
+
+}  // extern "C"

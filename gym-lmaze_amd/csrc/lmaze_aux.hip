@@ -1,0 +1,228 @@
+// lmaze_aux.hip -- the kernels either side of the step path: masked on-device reset
+// (reference reset(): lmaze_env.py:64-110, lmaze_env_v3.py:134-167) and the
+// reference-layout x E nearest-neighbour render (lmaze_env.py:217-234).
+#include "lmaze_common.h"
+
+namespace lmaze {
+
+
+// Philox4x32-10 (Salmon, Moraes, Dror, Shaw: "Parallel random numbers: as easy as 1, 2, 3", SC'11)
+__device__ __forceinline__ uint4 philox4x32_10(uint4 c, uint2 k) {
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        const uint32_t hi0 = __umulhi(0xD2511F53u, c.x), lo0 = 0xD2511F53u * c.x;
+        const uint32_t hi1 = __umulhi(0xCD9E8D57u, c.z), lo1 = 0xCD9E8D57u * c.z;
+        c = make_uint4(hi1 ^ c.y ^ k.x, lo1, hi0 ^ c.w ^ k.y, lo0);
+        k.x += 0x9E3779B9u;
+        k.y += 0xBB67AE85u;
+    }
+    return c;
+}
+
+__device__ __forceinline__ uint4 env_draw(const ResetArgs& a, int64_t local) {
+    const uint64_t e = (uint64_t)(a.env_base + local);
+    return philox4x32_10(make_uint4((uint32_t)e, (uint32_t)(e >> 32), (uint32_t)a.epoch,
+                                    (uint32_t)(a.epoch >> 32)),
+                         make_uint2((uint32_t)a.seed, (uint32_t)(a.seed >> 32)));
+}
+
+// cells the reference's rejection loops accept.  v0:73 ball: not 'W', not 'X'.
+// v3:149 goal: not 'W' (the ball list is the same list minus the goal cell, v3:158).
+template <int VARIANT>
+__device__ __forceinline__ bool spawn_ok(uint8_t c) {
+    return VARIANT == LMAZE_VARIANT_V3 ? (c != 'W') : (c != 'W' && c != 'X');
+}
+
+__device__ __forceinline__ bool interior(int cell, int G) {
+    const int x = cell / G, y = cell - x * G;
+    return x >= 1 && x <= G - 2 && y >= 1 && y <= G - 2;
+}
+
+__device__ __forceinline__ void write_reset(const ResetArgs& a, int64_t e) {
+    a.step_count[e] = 0;  // v0:110
+    a.reward[e] = -0.0f;  // v0:109
+    a.done[e] = 0;
+}
+
+// Shared layout: wave 0 compacts the accepted cells (row-major) into LDS once per
+// workgroup, then one lane per env indexes the list.
+template <int VARIANT>
+__global__ __launch_bounds__(LMAZE_BLOCK) void reset_shared_kernel(const ResetArgs a) {
+    extern __shared__ int4 lds4[];
+    uint16_t* list = reinterpret_cast<uint16_t*>(lds4);
+    __shared__ int count_s;
+    const int G = a.grid, CELLS = G * G;
+    const int tid = threadIdx.x;
+    if (tid < 64) {
+        int count = 0;
+        for (int base = 0; base < CELLS; base += 64) {
+            const int cell = base + tid;
+            const bool ok = cell < CELLS && interior(cell, G) && spawn_ok<VARIANT>(a.layout[cell]);
+            const unsigned long long m = __ballot(ok);
+            if (ok) list[count + __popcll(m & ((1ull << tid) - 1ull))] = (uint16_t)cell;
+            count += __popcll(m);
+        }
+        if (tid == 0) count_s = count;
+    }
+    __syncthreads();
+    const int64_t e = (int64_t)blockIdx.x * LMAZE_BLOCK + tid;
+    if (e >= a.n) return;
+    if (a.mask && !a.mask[e]) return;
+    const int count = count_s;
+    const uint4 r = env_draw(a, e);
+    if (VARIANT == LMAZE_VARIANT_V3) {
+        int kg = -1;
+        if (count > 0) {
+            kg = (int)__umulhi(r.x, (uint32_t)count);
+            const int cell = list[kg];
+            a.goal[e] = make_int2(cell / G, cell % G);
+        }
+        if (count > 1) {
+            int kb = (int)__umulhi(r.y, (uint32_t)(count - 1));
+            kb += (kb >= kg);
+            const int cell = list[kb];
+            a.ball[e] = make_int2(cell / G, cell % G);
+        }
+    } else if (count > 0) {
+        const int cell = list[__umulhi(r.y, (uint32_t)count)];
+        a.ball[e] = make_int2(cell / G, cell % G);
+    }
+    write_reset(a, e);
+}
+
+// k-th accepted cell of one env's own layout, found by a whole wave (all lanes call this)
+template <int VARIANT>
+__device__ __forceinline__ int wave_kth_cell(const uint8_t* lay, int G, int CELLS, int k, int lane) {
+    int seen = 0, found = -1;
+    for (int base = 0; base < CELLS; base += 64) {
+        const int cell = base + lane;
+        const bool ok = cell < CELLS && interior(cell, G) && spawn_ok<VARIANT>(lay[cell]);
+        const unsigned long long m = __ballot(ok);
+        const int rank = seen + __popcll(m & ((1ull << lane) - 1ull));
+        const unsigned long long hit = __ballot(ok && rank == k);
+        if (hit) found = base + __ffsll((long long)hit) - 1;
+        seen += __popcll(m);
+    }
+    return found;
+}
+
+// Per-env layouts: one wave per env scans that env's G*G bytes (coalesced) with ballots.
+template <int VARIANT>
+__global__ __launch_bounds__(LMAZE_BLOCK) void reset_perenv_kernel(const ResetArgs a) {
+    const int G = a.grid, CELLS = G * G;
+    const int lane = threadIdx.x & 63;
+    const int64_t e = (int64_t)blockIdx.x * (LMAZE_BLOCK / 64) + (threadIdx.x >> 6);
+    if (e >= a.n) return;
+    if (a.mask && !a.mask[e]) return;
+    const uint8_t* lay = a.layout + (size_t)e * CELLS;
+    int count = 0;
+    for (int base = 0; base < CELLS; base += 64) {
+        const int cell = base + lane;
+        const bool ok = cell < CELLS && interior(cell, G) && spawn_ok<VARIANT>(lay[cell]);
+        count += __popcll(__ballot(ok));
+    }
+    const uint4 r = env_draw(a, e);
+    if (VARIANT == LMAZE_VARIANT_V3) {
+        int kg = -1;
+        if (count > 0) {
+            kg = (int)__umulhi(r.x, (uint32_t)count);
+            const int cell = wave_kth_cell<VARIANT>(lay, G, CELLS, kg, lane);
+            if (lane == 0) a.goal[e] = make_int2(cell / G, cell % G);
+        }
+        if (count > 1) {
+            int kb = (int)__umulhi(r.y, (uint32_t)(count - 1));
+            kb += (kb >= kg);
+            const int cell = wave_kth_cell<VARIANT>(lay, G, CELLS, kb, lane);
+            if (lane == 0) a.ball[e] = make_int2(cell / G, cell % G);
+        }
+    } else if (count > 0) {
+        const int cell = wave_kth_cell<VARIANT>(lay, G, CELLS, (int)__umulhi(r.y, (uint32_t)count), lane);
+        if (lane == 0) a.ball[e] = make_int2(cell / G, cell % G);
+    }
+    if (lane == 0) write_reset(a, e);
+}
+
+hipError_t launch_reset(int variant, const ResetArgs& a, int layout_mode, hipStream_t s) {
+    if (a.n == 0) return hipSuccess;
+    const bool v3 = variant == LMAZE_VARIANT_V3;
+    if (layout_mode == LMAZE_LAYOUT_SHARED) {
+        const unsigned blocks = (unsigned)((a.n + LMAZE_BLOCK - 1) / LMAZE_BLOCK);
+        const size_t lds = ((size_t)a.grid * a.grid * 2 + 15) & ~(size_t)15;
+        if (v3) hipLaunchKernelGGL(reset_shared_kernel<LMAZE_VARIANT_V3>, dim3(blocks), dim3(LMAZE_BLOCK), lds, s, a);
+        else hipLaunchKernelGGL(reset_shared_kernel<LMAZE_VARIANT_V0>, dim3(blocks), dim3(LMAZE_BLOCK), lds, s, a);
+    } else {
+        const int epb = LMAZE_BLOCK / 64;
+        const unsigned blocks = (unsigned)((a.n + epb - 1) / epb);
+        if (v3) hipLaunchKernelGGL(reset_perenv_kernel<LMAZE_VARIANT_V3>, dim3(blocks), dim3(LMAZE_BLOCK), 0, s, a);
+        else hipLaunchKernelGGL(reset_perenv_kernel<LMAZE_VARIANT_V0>, dim3(blocks), dim3(LMAZE_BLOCK), 0, s, a);
+    }
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------
+// Reference-layout render: out[i, c, x*E+xx, y*E+yy] = float((obs[i,x,y] & mask[c]) != 0)
+// One workgroup per env; the env's G*G ints and two row/column maps sit in LDS; lanes
+// stripe the env's contiguous C*S*S floats with 16-byte stores.
+// ------------------------------------------------------------------------------------
+
+__global__ __launch_bounds__(LMAZE_BLOCK) void render_expanded_kernel(const ExpandArgs a) {
+    extern __shared__ int4 lds4[];
+    const int G = a.grid, E = a.expansion, C = a.channels;
+    const int CELLS = G * G, S = G * E, PLANE = S * S, L = C * PLANE;
+    int* cells = reinterpret_cast<int*>(lds4);                      // [CELLS]
+    int* maskl = cells + CELLS;                                     // [LMAZE_MAX_CHANNELS]
+    uint16_t* rowmap = reinterpret_cast<uint16_t*>(maskl + LMAZE_MAX_CHANNELS);  // [S] row -> (row / E) * G
+    uint16_t* colmap = rowmap + S;                                  // [S] col -> col / E
+    const int tid = threadIdx.x;
+    if (tid < LMAZE_MAX_CHANNELS) maskl[tid] = tid < C ? a.mask[tid] : 0;
+    for (int64_t i = blockIdx.x; i < a.n; i += gridDim.x) {
+        __syncthreads();
+        for (int k = tid; k < CELLS; k += LMAZE_BLOCK) cells[k] = a.obs[(size_t)i * CELLS + k];
+        for (int k = tid; k < S; k += LMAZE_BLOCK) {
+            rowmap[k] = (uint16_t)((k / E) * G);
+            colmap[k] = (uint16_t)(k / E);
+        }
+        __syncthreads();
+        const size_t B = (size_t)i * L;
+        const size_t a0 = (B + 3) & ~(size_t)3, a1 = (B + L) & ~(size_t)3;
+        auto value = [&](int local) -> float {
+            const int c = local / PLANE;
+            const int rem = local - c * PLANE;
+            const int row = rem / S, col = rem - row * S;
+            return (cells[rowmap[row] + colmap[col]] & maskl[c]) ? 1.0f : 0.0f;
+        };
+        // ragged head/tail (only when C*S*S is not a multiple of 4)
+        if (tid < (int)(a0 - B)) a.out[B + tid] = value(tid);
+        if (tid < (int)(B + L - a1)) a.out[a1 + tid] = value((int)(a1 - B) + tid);
+        const int nq = (int)((a1 - a0) >> 2);
+        float4* out4 = reinterpret_cast<float4*>(a.out + a0);
+        const int head = (int)(a0 - B);
+        for (int q = tid; q < nq; q += LMAZE_BLOCK) {
+            const int local = head + (q << 2);
+            int c = local / PLANE;
+            int rem = local - c * PLANE;
+            int row = rem / S, col = rem - row * S;
+            float v[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                v[j] = (cells[rowmap[row] + colmap[col]] & maskl[c]) ? 1.0f : 0.0f;
+                if (++col == S) {
+                    col = 0;
+                    if (++row == S) { row = 0; ++c; }
+                }
+            }
+            out4[q] = make_float4(v[0], v[1], v[2], v[3]);
+        }
+    }
+}
+
+hipError_t launch_expand(const ExpandArgs& a, hipStream_t s) {
+    if (a.n == 0) return hipSuccess;
+    const int S = a.grid * a.expansion;
+    const size_t lds = (((size_t)a.grid * a.grid * 4 + LMAZE_MAX_CHANNELS * 4 + (size_t)S * 4) + 15) & ~(size_t)15;
+    const unsigned blocks = (unsigned)(a.n < 65536 ? a.n : 65536);
+    hipLaunchKernelGGL(render_expanded_kernel, dim3(blocks), dim3(LMAZE_BLOCK), lds, s, a);
+    return hipGetLastError();
+}
+
+}  // namespace lmaze

@@ -1,0 +1,292 @@
+// lmaze_step.hip -- the hot path: one kernel per step() of N independent mazes, gfx950.
+//
+// Replaces the body of the reference's step() (gym_lmaze/envs/lmaze_env.py:146-237,
+// lmaze_env_v3.py:220-402): action decode, wall-collision check, position update,
+// reward/done, and the full re-render of the observation planes.
+//
+// Shape of the work (DESIGN.md "Kernels"): per env 37 B of state traffic and 4*G*G B of
+// observation written -- an HBM-write-bound stream with integer indexing, no MFMA.
+//   phase 1  one lane per env: coalesced SoA loads, transition against the layout held in
+//            LDS, coalesced SoA stores; the new ball cell goes to LDS.
+//   phase 2  the workgroup's envs own one contiguous [envs*G*G] dword range of obs; lanes
+//            stripe across it with 16-byte stores (1 KiB per wave instruction), so the
+//            write is perfectly coalesced whatever G is.  Shared layout: the ball-free
+//            pattern of a 16-byte-periodic group of envs is precomputed in LDS, so a
+//            store costs one ds_read_b128 + a few compares.  Per-env layouts: the
+//            workgroup's layouts are tiled into LDS first (one coalesced read), and both
+//            the collision check and the render read them from there.
+#include "lmaze_common.h"
+
+namespace lmaze {
+
+// ------------------------------------------------------------------------------------
+// Shared layout.  GT = G known at compile time (0: read it from the args).
+// ------------------------------------------------------------------------------------
+template <int GT, int VARIANT, bool DO_STEP>
+__global__ __launch_bounds__(LMAZE_BLOCK) void step_shared_kernel(const StepArgs a) {
+    constexpr int EPB = LMAZE_BLOCK;  // envs per workgroup = one lane per env in phase 1
+    constexpr bool V3 = VARIANT == LMAZE_VARIANT_V3;
+    const int G = GT ? GT : a.grid;
+    const int CELLS = G * G;
+    // envs per 16-byte period of the obs stream: G even -> an env is a whole number of
+    // 16-byte stores; G odd -> four envs are (G*G ints each, 4*G*G ints = G*G stores)
+    const int GRP = (GT != 0 && (G & 1)) ? 4 : 1;
+    const int PAT = (GT != 0) ? GRP * CELLS : CELLS;  // dwords of ball-free pattern kept in LDS
+
+    extern __shared__ int4 lds4[];
+    int* pat = reinterpret_cast<int*>(lds4);
+    int* ballflat = pat + PAT;
+    int* goalflat = ballflat + EPB;
+    uint8_t* lay = reinterpret_cast<uint8_t*>(goalflat + EPB);
+
+    const int tid = threadIdx.x;
+    const int64_t blockbase = (int64_t)blockIdx.x * EPB;
+    const int nb = (int)min((int64_t)EPB, a.n - blockbase);  // envs in this workgroup
+    const int64_t e = blockbase + tid;
+    const bool live = tid < nb;
+
+    // issue this lane's state loads first so their latency overlaps the LDS set-up
+    int2 b = make_int2(0, 0), g = make_int2(-1, -1);
+    if (live) {
+        b = a.ball[e];
+        if (V3) g = a.goal[e];
+    }
+
+    for (int i = tid; i < CELLS; i += LMAZE_BLOCK) lay[i] = a.layout[i];
+    for (int i = tid; i < PAT; i += LMAZE_BLOCK) {
+        const int c = (GT != 0 && GRP > 1) ? i % CELLS : i;
+        pat[i] = cell_bits<VARIANT>(a.layout[c]);
+    }
+    __syncthreads();
+
+    if (live) {
+        int bx = clampi(b.x, 0, G - 1), by = clampi(b.y, 0, G - 1);
+        if (DO_STEP) transition<VARIANT>(a, lay, G, e, bx, by, g.x, g.y);
+        const int off = (GT != 0) ? (tid % GRP) * CELLS : 0;
+        ballflat[tid] = off + bx * G + by;
+        if (V3) goalflat[tid] = (g.x >= 0 && g.x < G && g.y >= 0 && g.y < G) ? off + g.x * G + g.y : -8;
+    } else {
+        ballflat[tid] = -8;
+        if (V3) goalflat[tid] = -8;
+    }
+    if (a.obs == nullptr) return;
+    __syncthreads();
+
+    int32_t* obs = a.obs + (size_t)blockbase * CELLS;
+    int4* obs4 = reinterpret_cast<int4*>(obs);
+    const int R = nb * CELLS;  // dwords this workgroup writes
+    const int nq = R >> 2;     // whole 16-byte stores
+
+    if (GT != 0) {
+        const int V4G = PAT >> 2;  // stores per group of GRP envs
+        const int4* pat4 = reinterpret_cast<const int4*>(pat);
+        for (int q = tid; q < nq; q += LMAZE_BLOCK) {
+            const int grp = q / V4G;
+            const int p = q - grp * V4G;
+            int4 v = pat4[p];
+            const int p4 = p << 2;
+            if (GRP == 4) {
+                const int4 bf = reinterpret_cast<const int4*>(ballflat)[grp];
+                or_at(v, bf.x - p4, LMAZE_OBS_BALL);
+                or_at(v, bf.y - p4, LMAZE_OBS_BALL);
+                or_at(v, bf.z - p4, LMAZE_OBS_BALL);
+                or_at(v, bf.w - p4, LMAZE_OBS_BALL);
+                if (V3) {
+                    const int4 gf = reinterpret_cast<const int4*>(goalflat)[grp];
+                    or_at(v, gf.x - p4, LMAZE_OBS_GOAL);
+                    or_at(v, gf.y - p4, LMAZE_OBS_GOAL);
+                    or_at(v, gf.z - p4, LMAZE_OBS_GOAL);
+                    or_at(v, gf.w - p4, LMAZE_OBS_GOAL);
+                }
+            } else {
+                or_at(v, ballflat[grp] - p4, LMAZE_OBS_BALL);
+                if (V3) or_at(v, goalflat[grp] - p4, LMAZE_OBS_GOAL);
+            }
+            obs4[q] = v;
+        }
+    } else {
+        for (int q = tid; q < nq; q += LMAZE_BLOCK) {
+            const int f0 = q << 2;
+            int le = f0 / CELLS;
+            int c = f0 - le * CELLS;
+            int vals[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                int v = pat[c];
+                v |= (ballflat[le] == c) ? LMAZE_OBS_BALL : 0;
+                if (V3) v |= (goalflat[le] == c) ? LMAZE_OBS_GOAL : 0;
+                vals[j] = v;
+                if (++c == CELLS) { c = 0; ++le; }
+            }
+            obs4[q] = make_int4(vals[0], vals[1], vals[2], vals[3]);
+        }
+    }
+    // ragged tail (last workgroup only, when nb*G*G is not a multiple of 4)
+    const int f = (nq << 2) + tid;
+    if (f < R) {
+        const int le = f / CELLS;
+        const int c = f - le * CELLS;
+        const int off = (GT != 0) ? (le % GRP) * CELLS : 0;
+        int v = pat[(GT != 0 && GRP > 1) ? off + c : c];
+        v |= (ballflat[le] == off + c) ? LMAZE_OBS_BALL : 0;
+        if (V3) v |= (goalflat[le] == off + c) ? LMAZE_OBS_GOAL : 0;
+        obs[f] = v;
+    }
+}
+
+// ------------------------------------------------------------------------------------
+// Per-env layouts: uint8[N,G,G] in HBM, tiled into LDS per workgroup.
+// ------------------------------------------------------------------------------------
+template <int GT, int VARIANT, bool DO_STEP>
+__global__ __launch_bounds__(LMAZE_BLOCK) void step_perenv_kernel(const StepArgs a) {
+    constexpr bool V3 = VARIANT == LMAZE_VARIANT_V3;
+    const int G = GT ? GT : a.grid;
+    const int CELLS = G * G;
+    const int EPB = a.envs_per_block;  // multiple of 16: keeps the tile base 16-byte aligned
+
+    extern __shared__ int4 lds4[];
+    uint8_t* tile = reinterpret_cast<uint8_t*>(lds4);  // [EPB*CELLS] layouts of this workgroup
+    const int tile_bytes = (EPB * CELLS + 15) & ~15;
+    int* ballcell = reinterpret_cast<int*>(tile + tile_bytes);  // [EPB+1]
+    int* goalcell = ballcell + EPB + 1;                         // [EPB+1]
+
+    const int tid = threadIdx.x;
+    const int64_t blockbase = (int64_t)blockIdx.x * EPB;
+    const int nb = (int)min((int64_t)EPB, a.n - blockbase);
+    const int64_t e = blockbase + tid;
+    const bool live = tid < nb;
+    const int R = nb * CELLS;  // layout bytes read == obs dwords written by this workgroup
+
+    int2 b = make_int2(0, 0), g = make_int2(-1, -1);
+    if (live) {
+        b = a.ball[e];
+        if (V3) g = a.goal[e];
+    }
+
+    // stage the layouts: 16 B per lane per instruction, ragged byte tail
+    const uint8_t* src = a.layout + (size_t)blockbase * CELLS;
+    const int n16 = R >> 4;
+    for (int i = tid; i < n16; i += LMAZE_BLOCK) lds4[i] = reinterpret_cast<const int4*>(src)[i];
+    for (int i = (n16 << 4) + tid; i < R; i += LMAZE_BLOCK) tile[i] = src[i];
+    __syncthreads();
+
+    if (tid <= EPB) {
+        if (live) {
+            int bx = clampi(b.x, 0, G - 1), by = clampi(b.y, 0, G - 1);
+            if (DO_STEP) transition<VARIANT>(a, tile + tid * CELLS, G, e, bx, by, g.x, g.y);
+            ballcell[tid] = bx * G + by;
+            if (V3) goalcell[tid] = (g.x >= 0 && g.x < G && g.y >= 0 && g.y < G) ? g.x * G + g.y : -8;
+        } else {
+            ballcell[tid] = -8;
+            if (V3) goalcell[tid] = -8;
+        }
+    }
+    if (a.obs == nullptr) return;
+    __syncthreads();
+
+    int32_t* obs = a.obs + (size_t)blockbase * CELLS;
+    int4* obs4 = reinterpret_cast<int4*>(obs);
+    const int nq = R >> 2;
+    const uint32_t* tile32 = reinterpret_cast<const uint32_t*>(tile);
+    const bool whole = (CELLS & 3) == 0;  // a 16-byte store never straddles two envs
+    for (int q = tid; q < nq; q += LMAZE_BLOCK) {
+        const uint32_t w = tile32[q];  // 4 layout cells
+        const int f0 = q << 2;
+        int le = f0 / CELLS;
+        int c = f0 - le * CELLS;
+        int vals[4];
+        if (whole) {
+            const int bc = ballcell[le] - c;
+            const int gc = V3 ? goalcell[le] - c : -8;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                int v = cell_bits<VARIANT>((uint8_t)(w >> (8 * j)));
+                v |= (bc == j) ? LMAZE_OBS_BALL : 0;
+                if (V3) v |= (gc == j) ? LMAZE_OBS_GOAL : 0;
+                vals[j] = v;
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                int v = cell_bits<VARIANT>((uint8_t)(w >> (8 * j)));
+                v |= (ballcell[le] == c) ? LMAZE_OBS_BALL : 0;
+                if (V3) v |= (goalcell[le] == c) ? LMAZE_OBS_GOAL : 0;
+                vals[j] = v;
+                if (++c == CELLS) { c = 0; ++le; }
+            }
+        }
+        obs4[q] = make_int4(vals[0], vals[1], vals[2], vals[3]);
+    }
+    const int f = (nq << 2) + tid;
+    if (f < R) {
+        const int le = f / CELLS;
+        const int c = f - le * CELLS;
+        int v = cell_bits<VARIANT>(tile[f]);
+        v |= (ballcell[le] == c) ? LMAZE_OBS_BALL : 0;
+        if (V3) v |= (goalcell[le] == c) ? LMAZE_OBS_GOAL : 0;
+        obs[f] = v;
+    }
+}
+
+// ------------------------------------------------------------------------------------
+// host launchers
+// ------------------------------------------------------------------------------------
+static size_t shared_lds_bytes(int G, bool specialised) {
+    const int cells = G * G;
+    const int pat = (specialised && (G & 1)) ? 4 * cells : cells;
+    return (size_t)pat * 4 + 2 * LMAZE_BLOCK * 4 + (size_t)((cells + 15) & ~15);
+}
+
+int perenv_envs_per_block(int G) {
+    const int cells = G * G;
+    int epb = (16384 / cells) & ~15;  // about 16 KiB of layouts per workgroup
+    if (epb < 16) epb = 16;
+    if (epb > LMAZE_BLOCK) epb = LMAZE_BLOCK;
+    return epb;
+}
+
+static size_t perenv_lds_bytes(int G, int epb) {
+    return (size_t)((epb * G * G + 15) & ~15) + 2 * (size_t)(epb + 1) * 4;
+}
+
+template <int GT, int VARIANT, bool DO_STEP>
+static hipError_t launch_one(const StepArgs& a, int layout_mode, hipStream_t s) {
+    if (a.n == 0) return hipSuccess;
+    if (layout_mode == LMAZE_LAYOUT_SHARED) {
+        const int64_t blocks = (a.n + LMAZE_BLOCK - 1) / LMAZE_BLOCK;
+        hipLaunchKernelGGL((step_shared_kernel<GT, VARIANT, DO_STEP>), dim3((unsigned)blocks), dim3(LMAZE_BLOCK),
+                           shared_lds_bytes(a.grid, GT != 0), s, a);
+    } else {
+        StepArgs b = a;
+        b.envs_per_block = perenv_envs_per_block(a.grid);
+        const int64_t blocks = (a.n + b.envs_per_block - 1) / b.envs_per_block;
+        hipLaunchKernelGGL((step_perenv_kernel<GT, VARIANT, DO_STEP>), dim3((unsigned)blocks), dim3(LMAZE_BLOCK),
+                           perenv_lds_bytes(a.grid, b.envs_per_block), s, b);
+    }
+    return hipGetLastError();
+}
+
+// Grid sizes the kernels are specialised for: the reference's shipped sizes (12, 14, 18)
+// and BASELINE.json's (8, 11, 32); any other G in [3, 64] takes the GT = 0 instantiation.
+template <int VARIANT, bool DO_STEP>
+static hipError_t dispatch_grid(const StepArgs& a, int layout_mode, hipStream_t s) {
+    switch (a.grid) {
+        case 8:  return launch_one<8, VARIANT, DO_STEP>(a, layout_mode, s);
+        case 11: return launch_one<11, VARIANT, DO_STEP>(a, layout_mode, s);
+        case 12: return launch_one<12, VARIANT, DO_STEP>(a, layout_mode, s);
+        case 14: return launch_one<14, VARIANT, DO_STEP>(a, layout_mode, s);
+        case 18: return launch_one<18, VARIANT, DO_STEP>(a, layout_mode, s);
+        case 32: return launch_one<32, VARIANT, DO_STEP>(a, layout_mode, s);
+        default: return launch_one<0, VARIANT, DO_STEP>(a, layout_mode, s);
+    }
+}
+
+hipError_t launch_step(int variant, bool do_step, const StepArgs& a, int layout_mode, hipStream_t s) {
+    if (variant == LMAZE_VARIANT_V3)
+        return do_step ? dispatch_grid<LMAZE_VARIANT_V3, true>(a, layout_mode, s)
+                       : dispatch_grid<LMAZE_VARIANT_V3, false>(a, layout_mode, s);
+    return do_step ? dispatch_grid<LMAZE_VARIANT_V0, true>(a, layout_mode, s)
+                   : dispatch_grid<LMAZE_VARIANT_V0, false>(a, layout_mode, s);
+}
+
+}  // namespace lmaze

@@ -1,0 +1,285 @@
+"""LmazeVecEnv: N independent L-mazes held as struct-of-arrays torch tensors in HBM and
+stepped by one HIP kernel per step() through the C ABI of include/lmaze.h.
+
+Host side only: buffer ownership, argument marshalling, stream selection.  All arithmetic
+of the path (collision check, position update, reward/done, plane render, xE render,
+masked reset) runs in liblmaze_hip.so; there is no CPU implementation in this package.
+
+Reference semantics: gym_lmaze/envs/lmaze_env.py (v0) and lmaze_env_v3.py (v3).
+"""
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import _abi
+from . import layouts as L
+
+# per-variant constants the reference hard-codes in __init__
+VARIANTS = {
+    # lmaze_env.py:16-25, planes lmaze_env.py:208-215 (ball, wall, goal, blank)
+    "v0": dict(id=_abi.VARIANT_V0, layout=L.V0_GRID_12, expansion=7, step_limit=100,
+               rewards=(-1.0, -0.01, 100.0), channel_mask=(_abi.OBS_BALL, _abi.OBS_WALL, _abi.OBS_GOAL, _abi.OBS_FREE),
+               n_actions=4),
+    # lmaze_env_v3.py:76-99, planes lmaze_env_v3.py:291-293 (free, ball, goal)
+    "v3": dict(id=_abi.VARIANT_V3, layout=L.V3_GRID_18, expansion=4, step_limit=100,
+               rewards=(-1.0, -0.01, 100.0), channel_mask=(_abi.OBS_FREE, _abi.OBS_BALL, _abi.OBS_GOAL),
+               n_actions=4),
+}
+
+
+def _align(n, a=256):
+    return (n + a - 1) // a * a
+
+
+def resolve_device(device):
+    if device is None:
+        device = "cuda"
+    device = torch.device(device)
+    if device.type != "cuda":
+        raise RuntimeError("gym-lmaze_amd runs on MI355X only (device=%r): the HIP kernels are the "
+                           "only implementation of the step path, there is no CPU fallback" % (device,))
+    if not torch.cuda.is_available():
+        raise RuntimeError("gym-lmaze_amd: no HIP device visible; the step path cannot run")
+    if device.index is None:
+        device = torch.device("cuda", torch.cuda.current_device())
+    return device
+
+
+class LmazeVecEnv(object):
+    """N mazes with `variant` transition rules.
+
+    layout            one layout for every env: row strings / char array / uint8[G,G]
+                      (default: the reference's shipped layout for the variant)
+    per_env_layouts   uint8[N,G,G] (numpy or torch): every env has its own maze
+    env_base          global index of local env 0 when the batch is one shard of a larger
+                      one (keys the reset draws; see include/lmaze.h lmaze_reset)
+    """
+
+    def __init__(self, num_envs, variant="v0", layout=None, per_env_layouts=None, device=None,
+                 expansion=None, step_limit=None, rewards=None, seed=0, env_base=0, validate=True):
+        if variant not in VARIANTS:
+            raise ValueError("unknown variant %r (have %s)" % (variant, sorted(VARIANTS)))
+        spec = VARIANTS[variant]
+        self.variant = variant
+        self.num_envs = int(num_envs)
+        if self.num_envs < 1:
+            raise ValueError("num_envs must be >= 1")
+        self.device = resolve_device(device)
+        self.expansion = int(expansion if expansion is not None else spec["expansion"])
+        self.step_limit = int(step_limit if step_limit is not None else spec["step_limit"])
+        self.rewards = tuple(float(r) for r in (rewards if rewards is not None else spec["rewards"]))
+        self.channel_mask = spec["channel_mask"]
+        self.seed = int(seed)
+        self.env_base = int(env_base)
+        self._epoch = 0
+        self._is_v3 = variant == "v3"
+
+        N = self.num_envs
+        if per_env_layouts is not None:
+            lay = per_env_layouts
+            if not isinstance(lay, torch.Tensor):
+                lay = torch.from_numpy(L.to_codes(np.asarray(lay)))
+            if lay.dtype != torch.uint8 or lay.dim() != 3 or lay.shape[0] != N or lay.shape[1] != lay.shape[2]:
+                raise ValueError("per_env_layouts must be uint8[N,G,G]")
+            lay = lay.to(self.device).contiguous()
+            if validate:
+                _validate_on_device(lay, need_goal=not self._is_v3)
+            self.layout_mode = _abi.LAYOUT_PER_ENV
+            self.layout = lay
+        else:
+            codes = L.to_codes(layout if layout is not None else spec["layout"])
+            if codes.ndim != 2:
+                raise ValueError("layout must be [G,G]; use per_env_layouts for [N,G,G]")
+            if validate:
+                L.validate(codes, need_goal_marker=not self._is_v3)
+            self.layout_mode = _abi.LAYOUT_SHARED
+            self.layout = torch.from_numpy(codes).to(self.device)
+        self.grid = int(self.layout.shape[-1])
+        if not (3 <= self.grid <= _abi.MAX_GRID):
+            raise ValueError("grid side must be in [3, %d]" % _abi.MAX_GRID)
+        G = self.grid
+
+        # one allocation for all per-env scalars, so a host mirror is a single copy
+        sizes = [("ball_xy", 8 * N), ("goal_xy", 8 * N), ("step_count", 4 * N), ("reward", 4 * N),
+                 ("goal_count", 4 * N), ("done", N)]
+        offs, total = {}, 0
+        for name, sz in sizes:
+            offs[name] = total
+            total += _align(sz)
+        self._state = torch.zeros(total, dtype=torch.uint8, device=self.device)
+
+        def view(name, nbytes, dtype, shape):
+            return self._state[offs[name]:offs[name] + nbytes].view(dtype).view(shape)
+
+        self.ball_xy = view("ball_xy", 8 * N, torch.int32, (N, 2))
+        self.goal_xy = view("goal_xy", 8 * N, torch.int32, (N, 2))
+        self.step_count = view("step_count", 4 * N, torch.int32, (N,))
+        self.reward = view("reward", 4 * N, torch.float32, (N,))
+        self.goal_count = view("goal_count", 4 * N, torch.int32, (N,))
+        self._done_u8 = view("done", N, torch.uint8, (N,))
+        self.done = self._done_u8.view(torch.bool)
+        self.obs = torch.zeros((N, G, G), dtype=torch.int32, device=self.device)
+        self._expanded = None
+
+        self.params = _abi.make_params(spec["id"], G, self.layout_mode, self.step_limit, *self.rewards)
+        self._pp = C.byref(self.params)
+        self._cmask = (C.c_int32 * len(self.channel_mask))(*self.channel_mask)
+        self._bind_pointers()
+
+        if not self._is_v3:
+            # v0 looks the goal up once from the layout (lmaze_env.py:100-102): first 'X', row-major
+            self._fill_goal_from_layout()
+        self.reset()
+
+    # ------------------------------------------------------------------ plumbing
+    def _bind_pointers(self):
+        self._p_layout = self.layout.data_ptr()
+        self._p_ball = self.ball_xy.data_ptr()
+        self._p_goal = self.goal_xy.data_ptr()
+        self._p_step = self.step_count.data_ptr()
+        self._p_reward = self.reward.data_ptr()
+        self._p_done = self._done_u8.data_ptr()
+        self._p_gc = self.goal_count.data_ptr()
+        self._p_obs = self.obs.data_ptr()
+
+    def _stream(self):
+        return torch.cuda.current_stream(self.device).cuda_stream
+
+    def _guard(self):
+        return torch.cuda.device(self.device)
+
+    def _fill_goal_from_layout(self):
+        G = self.grid
+        flat = (self.layout.reshape(-1, G * G) == ord("X")).to(torch.int32)
+        has = flat.sum(dim=1) > 0
+        first = torch.argmax(flat, dim=1).to(torch.int32)
+        first = torch.where(has, first, torch.full_like(first, -1))
+        gx = torch.div(first, G, rounding_mode="floor")
+        gy = first - gx * G
+        g = torch.stack([gx, gy], dim=1).to(torch.int32)
+        self.goal_xy.copy_(g.expand(self.num_envs, 2) if g.shape[0] == 1 else g)
+
+    def _as_actions(self, actions):
+        if isinstance(actions, torch.Tensor):
+            a = actions
+            if a.device != self.device or a.dtype != torch.int32:
+                a = a.to(device=self.device, dtype=torch.int32)
+        else:
+            a = torch.as_tensor(np.asarray(actions, dtype=np.int64).astype(np.int32), device=self.device)
+        a = a.reshape(-1)
+        if a.numel() != self.num_envs:
+            raise ValueError("expected %d actions, got %d" % (self.num_envs, a.numel()))
+        return a.contiguous()
+
+    # ------------------------------------------------------------------ the hot path
+    def step(self, actions, render=True):
+        """One step() of every env.  Returns (obs, reward, done, actions): obs is the compact
+        int32[N,G,G] plane buffer (rewritten in place every step), reward float32[N], done
+        bool[N].  render=False skips the observation write (transition only)."""
+        a = self._as_actions(actions)
+        obs_ptr = self._p_obs if render else None
+        with self._guard():
+            if self._is_v3:
+                rc = _abi.lib.lmaze_step_v3(self._pp, self._p_layout, a.data_ptr(), self._p_ball, self._p_goal,
+                                            self._p_step, self._p_reward, self._p_done, obs_ptr,
+                                            self.num_envs, self._stream())
+            else:
+                rc = _abi.lib.lmaze_step_v0(self._pp, self._p_layout, a.data_ptr(), self._p_ball, self._p_step,
+                                            self._p_reward, self._p_done, self._p_gc, obs_ptr,
+                                            self.num_envs, self._stream())
+        _abi.check("lmaze_step_" + self.variant, rc)
+        return self.obs, self.reward, self.done, actions
+
+    def step_raw(self, action_ptr):
+        """step() on a raw device pointer to int32[N] actions (no tensor handling): for
+        rollouts over a pre-generated [T,N] action tensor, e.g. under graph capture."""
+        if self._is_v3:
+            rc = _abi.lib.lmaze_step_v3(self._pp, self._p_layout, action_ptr, self._p_ball, self._p_goal,
+                                        self._p_step, self._p_reward, self._p_done, self._p_obs,
+                                        self.num_envs, self._stream())
+        else:
+            rc = _abi.lib.lmaze_step_v0(self._pp, self._p_layout, action_ptr, self._p_ball, self._p_step,
+                                        self._p_reward, self._p_done, self._p_gc, self._p_obs,
+                                        self.num_envs, self._stream())
+        _abi.check("lmaze_step_" + self.variant, rc)
+
+    def observe(self):
+        """Re-render the compact planes of the current state (no transition)."""
+        with self._guard():
+            rc = _abi.lib.lmaze_observe(self._pp, self._p_layout, self._p_ball,
+                                        self._p_goal if self._is_v3 else None, self._p_obs,
+                                        self.num_envs, self._stream())
+        _abi.check("lmaze_observe", rc)
+        return self.obs
+
+    def reset(self, mask=None, seed=None):
+        """Masked on-device reset (mask: bool/uint8[N], None = all).  Returns the compact obs."""
+        if seed is not None:
+            self.seed = int(seed)
+            self._epoch = 0
+        m_ptr = None
+        if mask is not None:
+            m = mask if isinstance(mask, torch.Tensor) else torch.as_tensor(np.asarray(mask), device=self.device)
+            m = m.to(device=self.device)
+            m = (m.view(torch.uint8) if m.dtype == torch.bool else (m != 0).to(torch.uint8)).contiguous()
+            if m.numel() != self.num_envs:
+                raise ValueError("mask must have %d entries" % self.num_envs)
+            m_ptr = m.data_ptr()
+        with self._guard():
+            rc = _abi.lib.lmaze_reset(self._pp, self._p_layout, m_ptr, self.seed & (2 ** 64 - 1), self._epoch,
+                                      self.env_base, self._p_ball, self._p_goal if self._is_v3 else None,
+                                      self._p_step, self._p_reward, self._p_done, self._p_obs,
+                                      self.num_envs, self._stream())
+        _abi.check("lmaze_reset", rc)
+        self._epoch += 1
+        return self.obs
+
+    def set_state(self, ball_xy=None, goal_xy=None, step_count=None, reward=None, goal_count=None, done=None):
+        """Inject state (placement chosen by the caller, e.g. the reference's own RNG stream)."""
+        for dst, src in ((self.ball_xy, ball_xy), (self.goal_xy, goal_xy), (self.step_count, step_count),
+                         (self.reward, reward), (self.goal_count, goal_count), (self._done_u8, done)):
+            if src is not None:
+                t = src if isinstance(src, torch.Tensor) else torch.as_tensor(np.asarray(src))
+                dst.copy_(t.to(device=self.device).to(dst.dtype).reshape(dst.shape))
+
+    def expanded(self, out=None):
+        """Reference-layout observation float32[N,C,G*E,G*E] of the current compact planes
+        (the upsample loop of lmaze_env.py:217-234)."""
+        N, G, E, Cn = self.num_envs, self.grid, self.expansion, len(self.channel_mask)
+        if out is None:
+            if self._expanded is None:
+                self._expanded = torch.empty((N, Cn, G * E, G * E), dtype=torch.float32, device=self.device)
+            out = self._expanded
+        with self._guard():
+            rc = _abi.lib.lmaze_render_expanded(self._p_obs, G, E, self._cmask, Cn, out.data_ptr(), N,
+                                                self._stream())
+        _abi.check("lmaze_render_expanded", rc)
+        return out
+
+    def host_state(self):
+        """One device->host copy of every per-env scalar; returns numpy views."""
+        h = self._state.cpu().numpy()
+        base = self._state.data_ptr()
+
+        def v(t, dtype, shape):
+            off = t.data_ptr() - base
+            return h[off:off + t.numel() * t.element_size()].view(dtype).reshape(shape)
+
+        N = self.num_envs
+        return dict(ball_xy=v(self.ball_xy, np.int32, (N, 2)), goal_xy=v(self.goal_xy, np.int32, (N, 2)),
+                    step_count=v(self.step_count, np.int32, (N,)), reward=v(self.reward, np.float32, (N,)),
+                    goal_count=v(self.goal_count, np.int32, (N,)), done=v(self._done_u8, np.uint8, (N,)))
+
+
+def _validate_on_device(lay, need_goal=True):
+    W = ord("W")
+    ok = ((lay[:, 0, :] == W).all() & (lay[:, -1, :] == W).all() & (lay[:, :, 0] == W).all()
+          & (lay[:, :, -1] == W).all())
+    if not bool(ok):
+        raise ValueError("every layout needs a full 'W' border")
+    codes = torch.tensor([ord(c) for c in "WBSX"], dtype=torch.uint8, device=lay.device)
+    if not bool(torch.isin(lay, codes).all()):
+        raise ValueError("layout cells must be one of 'W', 'B', 'S', 'X'")
+    if need_goal and not bool((lay == ord("X")).flatten(1).any(dim=1).all()):
+        raise ValueError("a layout has no 'X' cell")

@@ -130,12 +130,14 @@ int lmaze_observe(const LmazeParams* params, const uint8_t* layout, const int32_
  * step_count = 0, reward = -0.0, done = 0, and a new ball cell (v3: first a new goal
  * cell) drawn uniformly from the cells the reference's rejection loop accepts
  * (v0:70-78: interior, not 'W', not 'X'; v3:147-161: goal interior not 'W', ball interior
- * not 'W' and != goal).  Draws come from Philox4x32-10 keyed by (seed, env index,
- * epoch); the reference draws from Python's global Mersenne Twister, so placement
- * parity with it is distributional, not bitwise.  obs (nullable) gets the reset planes.
+ * not 'W' and != goal).  Draws come from Philox4x32-10 keyed by (seed, env_base + i,
+ * epoch): env_base is the global index of this shard's env 0, so a batch sharded over
+ * several GPUs draws exactly what one GPU holding the whole batch would.  The reference
+ * draws from Python's global Mersenne Twister, so placement parity with it is
+ * distributional, not bitwise.  obs (nullable) gets the reset planes.
  */
 int lmaze_reset(const LmazeParams* params, const uint8_t* layout, const uint8_t* mask,
-                uint64_t seed, uint64_t epoch, int32_t* ball_xy, int32_t* goal_xy,
+                uint64_t seed, uint64_t epoch, int64_t env_base, int32_t* ball_xy, int32_t* goal_xy,
                 int32_t* step_count, float* reward, uint8_t* done, int32_t* obs, int64_t n,
                 void* stream);
 

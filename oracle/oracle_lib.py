@@ -92,10 +92,10 @@ def observe(p, layout, ball_xy, goal_xy, obs):
         raise RuntimeError("lmaze_oracle_observe -> %d" % rc)
 
 
-def reset(p, layout, mask, seed, epoch, ball_xy, goal_xy, step_count, reward, done, obs=None):
+def reset(p, layout, mask, seed, epoch, ball_xy, goal_xy, step_count, reward, done, obs=None, env_base=0):
     n = ball_xy.shape[0]
     rc = lib().lmaze_oracle_reset(C.byref(p), _p(layout, C.c_uint8), _p(mask, C.c_uint8),
-                                  C.c_uint64(seed), C.c_uint64(epoch), _p(ball_xy, C.c_int32),
+                                  C.c_uint64(seed), C.c_uint64(epoch), C.c_int64(env_base), _p(ball_xy, C.c_int32),
                                   _p(goal_xy, C.c_int32), _p(step_count, C.c_int32),
                                   _p(reward, C.c_float), _p(done, C.c_uint8), _p(obs, C.c_int32),
                                   C.c_int64(n))

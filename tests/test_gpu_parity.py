@@ -1,0 +1,354 @@
+"""GPU: the HIP step path (through the C ABI) against the golden fixtures and the C oracle.
+
+Bit-exact everywhere: integers, bytes, and float32 bit patterns of reward (incl. -0.0)."""
+import importlib
+import random
+
+import numpy as np
+import pytest
+import torch
+
+import oracle_lib as O
+from conftest import golden_files
+from helpers import (V0_CHANNEL_MASK, V3_CHANNEL_MASK, bordered_random_layouts, compact_to_ref_bits, f32_bits,
+                     load_golden, obs_hash, random_free_cells, ref_reward_bits)
+
+pytestmark = pytest.mark.gpu
+
+PKG = importlib.import_module("gym-lmaze_amd")
+L = PKG.layouts
+
+
+def _np(t):
+    return t.detach().cpu().numpy()
+
+
+# ----------------------------------------------------------------------------------------
+# 1. golden fixtures through the batched engine (N = 1, placement injected from the fixture)
+# ----------------------------------------------------------------------------------------
+def _replay_core(g, variant):
+    v3 = variant == "v3"
+    cmask = V3_CHANNEL_MASK if v3 else V0_CHANNEL_MASK
+    E = int(g["E"])
+    env = PKG.LmazeVecEnv(1, variant=variant, layout=g["layout"], expansion=E)
+    T = len(g["actions"])
+    n_reset = 0
+    for t in range(T):
+        if g["reset_before"][t]:
+            env.set_state(ball_xy=g["ball_before"][t:t + 1], step_count=np.zeros(1, np.int32),
+                          reward=np.array([-0.0], np.float32), done=np.zeros(1, np.uint8),
+                          goal_xy=g["goal_before"][t:t + 1] if v3 else None)
+            obs = _np(env.observe())
+            assert (compact_to_ref_bits(obs[0], cmask) == g["reset_planes"][n_reset]).all()
+            assert obs_hash(_np(env.expanded())[0]) == g["reset_hash"][n_reset]
+            n_reset += 1
+        obs, rew, done, _ = env.step(g["actions"][t:t + 1])
+        h = env.host_state()
+        assert f32_bits(h["reward"])[0] == ref_reward_bits(g["reward"][t]), t
+        assert h["done"][0] == g["done"][t], t
+        assert tuple(h["ball_xy"][0]) == tuple(g["ball"][t]), t
+        assert h["step_count"][0] == g["step_count"][t], t
+        if not v3:
+            assert h["goal_count"][0] == g["goal_count"][t], t   # persists across resets (lmaze_env.py:24)
+        assert (compact_to_ref_bits(_np(obs)[0], cmask) == g["planes"][t]).all(), t
+        assert obs_hash(_np(env.expanded())[0]) == g["obs_hash"][t], t
+
+
+@pytest.mark.parametrize("name", golden_files("v0_"))
+def test_hip_v0_matches_reference_fixture(name):
+    _replay_core(load_golden(name), "v0")
+
+
+@pytest.mark.parametrize("name", golden_files("v3_"))
+def test_hip_v3_matches_reference_fixture(name):
+    _replay_core(load_golden(name), "v3")
+
+
+# ----------------------------------------------------------------------------------------
+# 2. the drop-in classes end to end (BASELINE configs[0]): reference-typed returns, and the
+#    host reset consuming `random` in the reference's draw order reproduces its start cells
+# ----------------------------------------------------------------------------------------
+def test_dropin_v0_c1_rollout(capsys):
+    g = load_golden("v0_c1_g12_seed0")
+    import gym_lmaze
+    env = gym_lmaze.make("lmaze-v0")
+    assert "init-init" in capsys.readouterr().out
+    assert env.observation_space.shape == (4, 84, 84) and env.action_space.n == 4
+    random.seed(int(g["seed"]))
+    n_reset = 0
+    need_reset = True
+    for t in range(len(g["actions"])):
+        if need_reset:
+            o = env.reset()
+            assert isinstance(o, np.ndarray) and o.dtype == np.float32 and o.shape == (4, 84, 84)
+            assert obs_hash(o) == g["reset_hash"][n_reset]
+            assert (env.ball_x0, env.ball_y0) == tuple(g["ball_before"][t])
+            n_reset += 1
+            need_reset = False
+        a = int(g["actions"][t])
+        o, r, d, info = env.step(a)
+        assert type(r) is float and type(d) is bool and info == a and isinstance(o, np.ndarray)
+        assert r == g["reward"][t] and d == bool(g["done"][t]), t   # exact doubles, e.g. -0.01
+        assert obs_hash(o) == g["obs_hash"][t], t
+        assert (env.ball_x0, env.ball_y0) == tuple(g["ball"][t])
+        assert env.stepCount == g["step_count"][t]
+        need_reset = d
+    assert (env.goal_x, env.goal_y) == tuple(g["goal"])
+    assert env.state.shape == (4 * 12 * 12,) and env.state.dtype == np.float32
+
+
+def test_dropin_v0_resize_by_attribute_override():
+    """the reference is re-sized by overriding grid/realgrid/gridsize, then reset()."""
+    g = load_golden("v0_g11_open_seed0")
+    from gym_lmaze.envs import LmazeEnv
+    env = LmazeEnv()
+    env.grid = np.vectorize(chr)(g["layout"])
+    env.realgrid = 11
+    env.gridsize = 77
+    random.seed(int(g["seed"]))
+    need_reset, n_reset = True, 0
+    for t in range(150):
+        if need_reset:
+            o = env.reset()
+            assert o.shape == (4, 77, 77) and obs_hash(o) == g["reset_hash"][n_reset]
+            n_reset += 1
+            need_reset = False
+        o, r, d, _ = env.step(int(g["actions"][t]))
+        assert obs_hash(o) == g["obs_hash"][t] and np.float32(r).view(np.uint32) == ref_reward_bits(g["reward"][t])
+        need_reset = d
+
+
+def test_dropin_v3_strings_and_shared_buffer():
+    g = load_golden("v3_g18_seed0")
+    import gym_lmaze
+    env = gym_lmaze.make("lmaze-v3")
+    assert env.observation_space.shape == (3, 72, 72)
+    random.seed(int(g["seed"]))
+    need_reset, n_reset, first = True, 0, None
+    for t in range(len(g["actions"])):
+        if need_reset:
+            o = env.reset()
+            assert obs_hash(o) == g["reset_hash"][n_reset]
+            assert (env.goal_x, env.goal_y) == tuple(g["goal_before"][t])
+            n_reset += 1
+            need_reset = False
+        a = int(g["actions"][t])
+        arg = str(a) if 0 <= a <= 3 else a
+        o, r, d, info = env.step(arg)
+        first = o if first is None else first
+        assert o is first                      # one reused buffer (lmaze_env_v3.py:122,400)
+        assert info is arg or info == arg
+        assert r == g["reward"][t] and d == bool(g["done"][t]), t
+        assert obs_hash(o) == g["obs_hash"][t], t
+        need_reset = d
+    # named strings move too; an int never does (lmaze_env_v3.py:236-247)
+    env.reset(mode="test")
+    assert (env.ball_x0, env.ball_y0, env.goal_x, env.goal_y) == (7, 8, 8, 8)
+    env.step("left")
+    assert (env.ball_x0, env.ball_y0) == (6, 8)
+    env.step(1)
+    assert (env.ball_x0, env.ball_y0) == (6, 8)
+
+
+# ----------------------------------------------------------------------------------------
+# 3. batched engine vs the C oracle on identical seeded inputs
+# ----------------------------------------------------------------------------------------
+def _oracle_state(env, variant, layout_np):
+    h = env.host_state()
+    st = {k: np.array(v, copy=True) for k, v in h.items()}
+    p = O.params(O.VARIANT_V3 if variant == "v3" else O.VARIANT_V0, env.grid,
+                 O.LAYOUT_PER_ENV if layout_np.ndim == 3 else O.LAYOUT_SHARED, env.step_limit, *env.rewards)
+    return p, st
+
+
+def _compare_rollout(variant, N, G, T, shared=True, seed=0, render_every=1, action_hi=5, layout=None):
+    rs = np.random.RandomState(seed)
+    if shared:
+        lay = layout if layout is not None else bordered_random_layouts(1, G, seed + 100)[0]
+        env = PKG.LmazeVecEnv(N, variant=variant, layout=lay, seed=seed)
+        lay_all = np.broadcast_to(lay, (N, G, G))
+    else:
+        lay = bordered_random_layouts(N, G, seed + 100)
+        env = PKG.LmazeVecEnv(N, variant=variant, per_env_layouts=lay, seed=seed)
+        lay_all = lay
+    ball = random_free_cells(lay_all, seed + 1, forbid=(ord("W"),) if variant == "v3" else (ord("W"), ord("X")))
+    env.set_state(ball_xy=ball)
+    if variant == "v3":
+        env.set_state(goal_xy=random_free_cells(lay_all, seed + 2, forbid=(ord("W"),)))
+    p, st = _oracle_state(env, variant, lay)
+    lay_c = np.ascontiguousarray(lay)
+    obs_ref = np.zeros((N, G, G), np.int32)
+    for t in range(T):
+        # mostly legal ids, some out-of-range ones (-1 .. action_hi)
+        a = np.where(rs.rand(N) < 0.85, rs.randint(0, 4, N), rs.randint(-1, action_hi + 1, N)).astype(np.int32)
+        obs, rew, done, _ = env.step(torch.from_numpy(a))
+        if variant == "v3":
+            O.step_v3(p, lay_c, a, st["ball_xy"], st["goal_xy"], st["step_count"], st["reward"], st["done"], obs_ref)
+        else:
+            O.step_v0(p, lay_c, a, st["ball_xy"], st["step_count"], st["reward"], st["done"], st["goal_count"],
+                      obs_ref)
+        h = env.host_state()
+        for k in ("ball_xy", "step_count", "goal_count", "done"):
+            assert (h[k] == st[k]).all(), (k, t)
+        assert (f32_bits(h["reward"]) == f32_bits(st["reward"])).all(), t
+        if t % render_every == 0 or t == T - 1:
+            assert (_np(obs) == obs_ref).all(), t
+    return env, st
+
+
+def test_c2_65536_8x8_every_step_bit_exact():
+    """BASELINE configs[1]: 65 536 parallel 8x8 mazes, int32 state, bit-exact vs the CPU step()."""
+    _compare_rollout("v0", 65536, 8, 256, shared=True, seed=1, layout=L.to_codes(L.GRID_8_BORDERED))
+
+
+@pytest.mark.parametrize("G", [8, 11, 12, 14, 18, 32])
+@pytest.mark.parametrize("variant", ["v0", "v3"])
+def test_shared_layout_specialised_grids(variant, G):
+    # N not a multiple of 256 nor of 4: exercises the partial last workgroup and ragged tail
+    _compare_rollout(variant, 3003, G, 40, shared=True, seed=G)
+
+
+@pytest.mark.parametrize("G", [4, 5, 9, 10, 13, 21, 33, 64])
+@pytest.mark.parametrize("variant", ["v0", "v3"])
+def test_shared_layout_generic_grids(variant, G):
+    _compare_rollout(variant, 1030 if G < 40 else 300, G, 24, shared=True, seed=G)
+
+
+@pytest.mark.parametrize("G", [8, 11, 12, 32, 7, 9, 21, 40])
+@pytest.mark.parametrize("variant", ["v0", "v3"])
+def test_per_env_layouts(variant, G):
+    _compare_rollout(variant, 1537 if G < 40 else 200, G, 24, shared=False, seed=G + 7)
+
+
+@pytest.mark.parametrize("N", [1, 2, 3, 4, 5, 63, 64, 255, 256, 257, 511])
+def test_small_and_ragged_batches(N):
+    _compare_rollout("v0", N, 11, 12, shared=True, seed=N)
+    _compare_rollout("v0", N, 11, 8, shared=False, seed=N)
+
+
+def test_transition_only_leaves_obs_untouched():
+    env = PKG.LmazeVecEnv(1000, variant="v0", layout=L.open_room(11, (5, 5)))
+    before = env.obs.clone()
+    env.step(torch.randint(0, 4, (1000,), dtype=torch.int32), render=False)
+    assert (env.obs == before).all()
+    assert (env.step_count == 1).all()
+
+
+def test_sticky_reward_and_done_quirks_known_answers():
+    """Appendix B-1/2/3 on the 12x12 layout: sticky reward on 'S', in-place move on unknown id,
+    done only at stepCount == 100."""
+    env = PKG.LmazeVecEnv(1, variant="v0")
+    env.set_state(ball_xy=[[1, 2]], step_count=[0], reward=[-0.0])
+    env.step([0])                              # up into the border wall
+    assert float(env.reward[0]) == -1.0
+    env.step([2])                              # left into 'S' at (1,1): no branch fires
+    h = env.host_state()
+    assert tuple(h["ball_xy"][0]) == (1, 2) and h["reward"][0] == -1.0
+    env.step([7])                              # unknown id on a 'B' cell: moves in place, -0.01
+    h = env.host_state()
+    assert tuple(h["ball_xy"][0]) == (1, 2) and h["reward"][0] == np.float32(-0.01)
+    assert int(_np(env.obs)[0].__and__(1).sum()) == 1
+    env.set_state(step_count=[98])
+    assert not bool(env.step([7])[2][0])       # 99
+    env.set_state(step_count=[99])
+    assert bool(env.step([7])[2][0])           # stepCount == 100
+    assert not bool(env.step([7])[2][0])       # 101: False again
+    # goal: from (5,6)? 'X' is at (5,5); (4,5) is 'B' above it
+    env.set_state(ball_xy=[[4, 5]], step_count=[0], goal_count=[0])
+    _, r, d, _ = env.step([1])
+    assert float(r[0]) == 100.0 and bool(d[0]) and int(env.goal_count[0]) == 1
+    _, r, d, _ = env.step([9])                 # unknown id standing on 'X': scores again
+    assert float(r[0]) == 100.0 and int(env.goal_count[0]) == 2
+
+
+def test_v3_lookahead_known_answers():
+    """Appendix A v3: two cells short and stepping toward the goal scores; stepping onto it does not."""
+    env = PKG.LmazeVecEnv(1, variant="v3")
+    env.set_state(ball_xy=[[6, 8]], goal_xy=[[8, 8]], step_count=[0])
+    _, r, d, _ = env.step([1])                 # (6,8)->(7,8); look-ahead (8,8) == goal
+    assert float(r[0]) == 100.0 and bool(d[0])
+    _, r, d, _ = env.step([1])                 # onto the goal: look-ahead (9,8) != goal
+    assert float(r[0]) == np.float32(-0.01) and not bool(d[0])
+    _, r, d, _ = env.step([-1])                # no-op standing on the goal
+    assert float(r[0]) == 100.0
+    env.set_state(step_count=[99])
+    assert not bool(env.step([0])[2][0])       # 100 > 100 False
+    assert bool(env.step([0])[2][0])           # 101 > 100
+
+
+# ----------------------------------------------------------------------------------------
+# 4. reset kernel vs oracle (same Philox draws), and its distribution
+# ----------------------------------------------------------------------------------------
+@pytest.mark.parametrize("variant", ["v0", "v3"])
+@pytest.mark.parametrize("shared", [True, False])
+def test_reset_matches_oracle(variant, shared):
+    N, G, seed = 5000, 12, 1234
+    if shared:
+        lay = L.to_codes(L.V0_GRID_12)
+        env = PKG.LmazeVecEnv(N, variant=variant, layout=lay, seed=seed, env_base=77)
+    else:
+        lay = bordered_random_layouts(N, G, 5)
+        env = PKG.LmazeVecEnv(N, variant=variant, per_env_layouts=lay, seed=seed, env_base=77)
+    p, st = _oracle_state(env, variant, lay)
+    # constructor already ran epoch 0; replay it in the oracle from a zero state
+    for k in st:
+        st[k][...] = 0
+    st["goal_xy"][...] = _np(env.goal_xy) if variant == "v0" else 0
+    obs_ref = np.zeros((N, G, G), np.int32)
+    O.reset(p, np.ascontiguousarray(lay), None, seed, 0, st["ball_xy"], st["goal_xy"] if variant == "v3" else None,
+            st["step_count"], st["reward"], st["done"], obs_ref, env_base=77)
+    h = env.host_state()
+    assert (h["ball_xy"] == st["ball_xy"]).all()
+    if variant == "v3":
+        assert (h["goal_xy"] == st["goal_xy"]).all()
+    assert (_np(env.obs) == obs_ref).all()
+    assert (f32_bits(h["reward"]) == f32_bits(np.float32(-0.0))).all()
+    # masked second reset after some steps: only masked envs change
+    env.step(torch.randint(0, 4, (N,), dtype=torch.int32))
+    mask = np.random.RandomState(3).rand(N) < 0.3
+    h1 = {k: np.array(v, copy=True) for k, v in env.host_state().items()}
+    env.reset(mask=torch.from_numpy(mask))
+    O.reset(p, np.ascontiguousarray(lay), mask.astype(np.uint8), seed, 1, h1["ball_xy"],
+            h1["goal_xy"] if variant == "v3" else None, h1["step_count"], h1["reward"], h1["done"], obs_ref,
+            env_base=77)
+    h2 = env.host_state()
+    for k in ("ball_xy", "goal_xy", "step_count", "done"):
+        assert (h2[k] == h1[k]).all(), k
+    assert (f32_bits(h2["reward"]) == f32_bits(h1["reward"])).all()
+    assert (h2["step_count"][mask] == 0).all() and (h2["step_count"][~mask] == 1).all()
+    assert (_np(env.obs) == obs_ref).all()
+
+
+def test_reset_placement_is_uniform_over_accepted_cells():
+    lay = L.to_codes(L.V0_GRID_12)
+    N = 1 << 18
+    env = PKG.LmazeVecEnv(N, variant="v0", layout=lay, seed=9)
+    b = _np(env.ball_xy)
+    cells = b[:, 0] * 12 + b[:, 1]
+    ok = np.flatnonzero((lay.reshape(-1) != ord("W")) & (lay.reshape(-1) != ord("X")))
+    counts = np.bincount(cells, minlength=144)
+    assert counts[np.setdiff1d(np.arange(144), ok)].sum() == 0       # never a wall, never 'X'
+    expect = N / len(ok)
+    chi2 = ((counts[ok] - expect) ** 2 / expect).sum()
+    assert chi2 < 2.0 * len(ok)                                       # loose: ~len(ok) expected
+
+
+# ----------------------------------------------------------------------------------------
+# 5. reference-layout render vs oracle, incl. shapes whose C*S*S is not a multiple of 4
+# ----------------------------------------------------------------------------------------
+@pytest.mark.parametrize("G,E,cmask", [(12, 7, (1, 2, 4, 8)), (11, 7, (1, 2, 4, 8)), (18, 4, (8, 1, 4)),
+                                       (5, 7, (1, 2, 4, 8, 3)), (5, 7, (8, 4, 1)), (9, 3, (1, 2, 4)),
+                                       (32, 7, (1, 2, 4, 8)), (8, 1, (1,))])
+def test_render_expanded_matches_oracle(G, E, cmask):
+    abi = importlib.import_module("gym-lmaze_amd._abi")
+    import ctypes as C
+    N = 37
+    obs = np.random.RandomState(G * E).randint(0, 16, (N, G, G)).astype(np.int32)
+    ref = O.render_expanded(obs, G, E, cmask)
+    d_obs = torch.from_numpy(obs).cuda()
+    out = torch.full((N, len(cmask), G * E, G * E), -1.0, dtype=torch.float32, device="cuda")
+    m = (C.c_int32 * len(cmask))(*cmask)
+    rc = abi.lib.lmaze_render_expanded(d_obs.data_ptr(), G, E, m, len(cmask), out.data_ptr(), N,
+                                       torch.cuda.current_stream().cuda_stream)
+    assert rc == 0
+    assert (_np(out).view(np.uint32) == ref.view(np.uint32)).all()
