@@ -49,6 +49,9 @@ def cpu_baseline(G, layout_codes, budget_s=12.0):
     obs = np.zeros((N, G, G), np.int32)
     acts = [rs.randint(0, 4, N).astype(np.int32) for _ in range(8)]
     lay = np.ascontiguousarray(layout_codes)
+    # the GPU box gives one GPU's share of the host: 16 cores (gpurun notes); do not grab all 256
+    threads = max(1, min(16, len(os.sched_getaffinity(0))))
+    O.set_threads(threads)
     O.step_v0(p, lay, acts[0], ball, sc, rew, done, gc, obs)   # warm-up / page-in
     t0 = time.perf_counter()
     O.step_v0(p, lay, acts[1], ball, sc, rew, done, gc, obs)
@@ -58,8 +61,9 @@ def cpu_baseline(G, layout_codes, budget_s=12.0):
     for t in range(steps):
         O.step_v0(p, lay, acts[t & 7], ball, sc, rew, done, gc, obs)
     dt = time.perf_counter() - t0
-    return {"value": N * steps / dt, "unit": "env-steps/s", "cores": O.threads(), "kind": "port",
-            "sample": "%d envs x %d steps of the same 11x11 v0 workload, C oracle (OpenMP), %.1f s" % (N, steps, dt)}
+    return {"value": N * steps / dt, "unit": "env-steps/s", "cores": threads, "kind": "port",
+            "sample": "%d envs x %d steps of the same %dx%d v0 workload, C oracle (OpenMP, %d threads), %.1f s"
+                      % (N, steps, G, G, threads, dt)}
 
 
 def main():
@@ -67,15 +71,23 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=300)
     ap.add_argument("--warmup", type=int, default=30)
-    ap.add_argument("--envs", type=int, default=1 << 20, help="envs per GPU")
-    ap.add_argument("--grid", type=int, default=11)
-    ap.add_argument("--per-env-layouts", action="store_true", help="configs[4]-style: own random maze per env")
+    ap.add_argument("--workload", choices=["c3", "c2", "c5"], default="c3",
+                    help="c3 (default, the metric's config): 1 048 576 x 11x11 shared layout; "
+                         "c2: 65 536 x 8x8; c5: 1 048 576 x 32x32 with per-env random layouts")
+    ap.add_argument("--envs", type=int, default=None, help="envs per GPU (overrides the workload's)")
+    ap.add_argument("--grid", type=int, default=None)
+    ap.add_argument("--per-env-layouts", action="store_true", help="own random maze per env")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--action-rows", type=int, default=32, help="distinct pre-generated action rows (ring)")
     args = ap.parse_args()
 
     import numpy as np
     import torch
+
+    preset = {"c3": (1 << 20, 11, False), "c2": (65536, 8, False), "c5": (1 << 20, 32, True)}[args.workload]
+    args.envs = args.envs if args.envs is not None else preset[0]
+    args.grid = args.grid if args.grid is not None else preset[1]
+    args.per_env_layouts = args.per_env_layouts or preset[2]
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -97,7 +109,10 @@ def main():
     pkg = importlib.import_module("gym-lmaze_amd")
     G, N = args.grid, args.envs
     env_base = rank * N
-    layout = pkg.layouts.to_codes(pkg.layouts.open_room(G, (G // 2, G // 2)))
+    if args.workload == "c2":
+        layout = pkg.layouts.to_codes(pkg.layouts.GRID_8_BORDERED)   # lmaze_env.py:28-35 literal, bordered
+    else:
+        layout = pkg.layouts.to_codes(pkg.layouts.open_room(G, (G // 2, G // 2)))
     if args.per_env_layouts:
         gen = torch.Generator(device=dev).manual_seed(7 + rank)
         lay = torch.where(torch.rand((N, G, G), device=dev, generator=gen) < 0.25, ord("W"), ord("B")).to(torch.uint8)
@@ -125,12 +140,13 @@ def main():
         if dist is not None:
             dist.barrier()
         torch.cuda.synchronize()
-        ev = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
+        # HIP events on the stream the kernels are launched on (torch's current stream)
+        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         t0 = time.perf_counter()
-        ev[0].record()
+        ev0.record()
         for t in range(args.steps):
             env.step_raw(row_ptr[(args.warmup + t) % R])
-            ev[t + 1].record()
+        ev1.record()
         torch.cuda.synchronize()
         elapsed = time.perf_counter() - t0
         if dist is not None:
@@ -139,8 +155,7 @@ def main():
             dist.all_reduce(tt, op=dist.ReduceOp.MAX)
             elapsed = float(tt.item())
     # per-launch GPU time from HIP events recorded on the launch stream
-    per = np.array([ev[i].elapsed_time(ev[i + 1]) for i in range(args.steps)])  # ms
-    kern_ms = float(ev[0].elapsed_time(ev[-1]) / args.steps)
+    kern_ms = float(ev0.elapsed_time(ev1) / args.steps)   # ms per launch, launch gaps included
 
     # sanity: the run really stepped (every env advanced warmup+steps times)
     assert int(env.step_count.min().item()) == args.warmup + args.steps
@@ -161,6 +176,7 @@ def main():
                 traffic = None
         out = {
             "metric": "env steps/sec (whole node), 1M parallel 11x11 mazes at 1/2/4/8 MI355X",
+            "workload_id": args.workload,
             "value": value, "unit": "env-steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "int32", "data": "synthetic",
@@ -170,8 +186,7 @@ def main():
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "kernel": "lmaze::step_%s_kernel<%d, v0>" % ("perenv" if args.per_env_layouts else "shared", G),
-                         "bytes_per_env_step": B, "kernel_ms_avg": kern_ms,
-                         "kernel_ms_median": float(np.median(per)), "kernel_ms_min": float(per.min())},
+                         "bytes_per_env_step": B, "kernel_ms_avg": kern_ms},
         }
         if not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(G, layout)

@@ -119,6 +119,48 @@ __device__ __forceinline__ void transition(const StepArgs& a, const uint8_t* lay
     a.done[e] = dn ? 1 : 0;
 }
 
+// The same transition read off the LDS pattern of static plane bits instead of the layout
+// characters: WALL <=> 'W'; v0 FREE <=> 'B', GOAL <=> 'X', none <=> 'S' (no branch fires).
+template <int VARIANT>
+__device__ __forceinline__ void transition_bits(const StepArgs& a, const int* pat, int G, int64_t e,
+                                                int& bx, int& by, int gx, int gy) {
+    const int act = a.action[e];
+    const int sc = a.step_count[e] + 1;  // v0:151, v3:225
+    int ox, oy;
+    decode_action(act, ox, oy);
+    const int tx = clampi(bx + ox, 0, G - 1), ty = clampi(by + oy, 0, G - 1);
+    const int cb = pat[tx * G + ty];  // v0:172, v3:251
+    float r;
+    bool dn;
+    if (VARIANT == LMAZE_VARIANT_V3) {
+        r = -0.0f;  // v3:224
+        if (cb & LMAZE_OBS_WALL) {
+            r = a.reward_wall;  // v3:252
+        } else {
+            bx = tx; by = ty;   // v3:258-259
+            r = (bx + ox == gx && by + oy == gy) ? a.reward_goal : a.reward_move;  // v3:262-265
+        }
+        dn = (r == a.reward_goal) || (sc > a.step_limit);  // v3:398
+    } else {
+        r = a.reward[e];  // sticky: no else branch in v0:172-195
+        if (cb & LMAZE_OBS_WALL) {
+            r = a.reward_wall;  // v0:174
+        } else if (cb & LMAZE_OBS_FREE) {
+            bx = tx; by = ty;   // v0:180-181
+            r = a.reward_move;  // v0:184
+        } else if (cb & LMAZE_OBS_GOAL) {
+            bx = tx; by = ty;   // v0:190-191
+            r = a.reward_goal;  // v0:194
+            if (a.goal_count) a.goal_count[e] += 1;  // v0:195
+        }
+        dn = (r == a.reward_goal) || (sc == a.step_limit);  // v0:246-249
+    }
+    a.ball[e] = make_int2(bx, by);
+    a.step_count[e] = sc;
+    a.reward[e] = r;
+    a.done[e] = dn ? 1 : 0;
+}
+
 // OR `bit` into component d (0..3) of v; other d leave v unchanged
 __device__ __forceinline__ void or_at(int4& v, int d, int bit) {
     v.x |= (d == 0) ? bit : 0;

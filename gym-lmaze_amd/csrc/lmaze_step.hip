@@ -22,10 +22,22 @@ namespace lmaze {
 // ------------------------------------------------------------------------------------
 // Shared layout.  GT = G known at compile time (0: read it from the args).
 // ------------------------------------------------------------------------------------
-template <int GT, int VARIANT, bool DO_STEP>
+template <bool NT>
+__device__ __forceinline__ void store16(int4* p, const int4& v) {
+    typedef int v4i __attribute__((ext_vector_type(4)));
+    if (NT) {
+        v4i t = {v.x, v.y, v.z, v.w};
+        __builtin_nontemporal_store(t, reinterpret_cast<v4i*>(p));
+    } else {
+        *p = v;
+    }
+}
+
+// EPB = envs per workgroup (multiple of 4); NT = non-temporal obs stores
+template <int GT, int VARIANT, bool DO_STEP, int EPB = LMAZE_BLOCK, bool NT = false>
 __global__ __launch_bounds__(LMAZE_BLOCK) void step_shared_kernel(const StepArgs a) {
-    constexpr int EPB = LMAZE_BLOCK;  // envs per workgroup = one lane per env in phase 1
     constexpr bool V3 = VARIANT == LMAZE_VARIANT_V3;
+    static_assert(EPB % 4 == 0, "group alignment");
     const int G = GT ? GT : a.grid;
     const int CELLS = G * G;
     // envs per 16-byte period of the obs stream: G even -> an env is a whole number of
@@ -42,15 +54,6 @@ __global__ __launch_bounds__(LMAZE_BLOCK) void step_shared_kernel(const StepArgs
     const int tid = threadIdx.x;
     const int64_t blockbase = (int64_t)blockIdx.x * EPB;
     const int nb = (int)min((int64_t)EPB, a.n - blockbase);  // envs in this workgroup
-    const int64_t e = blockbase + tid;
-    const bool live = tid < nb;
-
-    // issue this lane's state loads first so their latency overlaps the LDS set-up
-    int2 b = make_int2(0, 0), g = make_int2(-1, -1);
-    if (live) {
-        b = a.ball[e];
-        if (V3) g = a.goal[e];
-    }
 
     for (int i = tid; i < CELLS; i += LMAZE_BLOCK) lay[i] = a.layout[i];
     for (int i = tid; i < PAT; i += LMAZE_BLOCK) {
@@ -59,15 +62,21 @@ __global__ __launch_bounds__(LMAZE_BLOCK) void step_shared_kernel(const StepArgs
     }
     __syncthreads();
 
-    if (live) {
-        int bx = clampi(b.x, 0, G - 1), by = clampi(b.y, 0, G - 1);
-        if (DO_STEP) transition<VARIANT>(a, lay, G, e, bx, by, g.x, g.y);
-        const int off = (GT != 0) ? (tid % GRP) * CELLS : 0;
-        ballflat[tid] = off + bx * G + by;
-        if (V3) goalflat[tid] = (g.x >= 0 && g.x < G && g.y >= 0 && g.y < G) ? off + g.x * G + g.y : -8;
-    } else {
-        ballflat[tid] = -8;
-        if (V3) goalflat[tid] = -8;
+    for (int le = tid; le < EPB; le += LMAZE_BLOCK) {  // one lane per env (EPB <= block: one pass)
+        if (le < nb) {
+            const int64_t e = blockbase + le;
+            const int2 b = a.ball[e];
+            int2 g = make_int2(-1, -1);
+            if (V3) g = a.goal[e];
+            int bx = clampi(b.x, 0, G - 1), by = clampi(b.y, 0, G - 1);
+            if (DO_STEP) transition<VARIANT>(a, lay, G, e, bx, by, g.x, g.y);
+            const int off = (GT != 0) ? (le % GRP) * CELLS : 0;
+            ballflat[le] = off + bx * G + by;
+            if (V3) goalflat[le] = (g.x >= 0 && g.x < G && g.y >= 0 && g.y < G) ? off + g.x * G + g.y : -8;
+        } else {
+            ballflat[le] = -8;
+            if (V3) goalflat[le] = -8;
+        }
     }
     if (a.obs == nullptr) return;
     __syncthreads();
@@ -102,7 +111,7 @@ __global__ __launch_bounds__(LMAZE_BLOCK) void step_shared_kernel(const StepArgs
                 or_at(v, ballflat[grp] - p4, LMAZE_OBS_BALL);
                 if (V3) or_at(v, goalflat[grp] - p4, LMAZE_OBS_GOAL);
             }
-            obs4[q] = v;
+            store16<NT>(obs4 + q, v);
         }
     } else {
         for (int q = tid; q < nq; q += LMAZE_BLOCK) {
@@ -118,7 +127,7 @@ __global__ __launch_bounds__(LMAZE_BLOCK) void step_shared_kernel(const StepArgs
                 vals[j] = v;
                 if (++c == CELLS) { c = 0; ++le; }
             }
-            obs4[q] = make_int4(vals[0], vals[1], vals[2], vals[3]);
+            store16<NT>(obs4 + q, make_int4(vals[0], vals[1], vals[2], vals[3]));
         }
     }
     // ragged tail (last workgroup only, when nb*G*G is not a multiple of 4)
@@ -231,10 +240,10 @@ __global__ __launch_bounds__(LMAZE_BLOCK) void step_perenv_kernel(const StepArgs
 // ------------------------------------------------------------------------------------
 // host launchers
 // ------------------------------------------------------------------------------------
-static size_t shared_lds_bytes(int G, bool specialised) {
+static size_t shared_lds_bytes(int G, bool specialised, int epb = LMAZE_BLOCK) {
     const int cells = G * G;
     const int pat = (specialised && (G & 1)) ? 4 * cells : cells;
-    return (size_t)pat * 4 + 2 * LMAZE_BLOCK * 4 + (size_t)((cells + 15) & ~15);
+    return (size_t)pat * 4 + 2 * (size_t)epb * 4 + (size_t)((cells + 15) & ~15);
 }
 
 int perenv_envs_per_block(int G) {
@@ -249,21 +258,55 @@ static size_t perenv_lds_bytes(int G, int epb) {
     return (size_t)((epb * G * G + 15) & ~15) + 2 * (size_t)(epb + 1) * 4;
 }
 
+// Obs buffers larger than this are written with non-temporal stores: they cannot stay in the
+// 256 MiB Infinity Cache anyway, and streaming them past L2 measured 0-7 % faster on MI355X;
+// smaller buffers keep plain stores so the consumer of the observation finds them on-die.
+static const size_t kNonTemporalObsBytes = (size_t)192 << 20;
+
+template <int GT, int VARIANT, bool DO_STEP, int EPB>
+static hipError_t launch_shared(const StepArgs& a, hipStream_t s) {
+    const int64_t blocks = (a.n + EPB - 1) / EPB;
+    const size_t lds = shared_lds_bytes(a.grid, GT != 0, EPB);
+    const bool nt = a.obs != nullptr && (size_t)a.n * a.grid * a.grid * 4 > kNonTemporalObsBytes;
+    if (nt)
+        hipLaunchKernelGGL((step_shared_kernel<GT, VARIANT, DO_STEP, EPB, true>), dim3((unsigned)blocks),
+                           dim3(LMAZE_BLOCK), lds, s, a);
+    else
+        hipLaunchKernelGGL((step_shared_kernel<GT, VARIANT, DO_STEP, EPB, false>), dim3((unsigned)blocks),
+                           dim3(LMAZE_BLOCK), lds, s, a);
+    return hipGetLastError();
+}
+
+template <int GT, int VARIANT, bool DO_STEP>
+static hipError_t launch_perenv(const StepArgs& a, hipStream_t s) {
+    StepArgs b = a;
+    b.envs_per_block = perenv_envs_per_block(a.grid);
+    const int64_t blocks = (a.n + b.envs_per_block - 1) / b.envs_per_block;
+    hipLaunchKernelGGL((step_perenv_kernel<GT, VARIANT, DO_STEP>), dim3((unsigned)blocks), dim3(LMAZE_BLOCK),
+                       perenv_lds_bytes(a.grid, b.envs_per_block), s, b);
+    return hipGetLastError();
+}
+
+// Envs per workgroup for the shared-layout kernel: about 32 KiB of observation per workgroup
+// (8 sixteen-byte stores per lane).  Measured at G=11 on MI355X (tools/kbench.hip): 64 envs
+// (31 KiB) 90-91 us per 1M-env step, 128/256 envs 96-101 us, 32 envs 120 us.
 template <int GT, int VARIANT, bool DO_STEP>
 static hipError_t launch_one(const StepArgs& a, int layout_mode, hipStream_t s) {
     if (a.n == 0) return hipSuccess;
-    if (layout_mode == LMAZE_LAYOUT_SHARED) {
-        const int64_t blocks = (a.n + LMAZE_BLOCK - 1) / LMAZE_BLOCK;
-        hipLaunchKernelGGL((step_shared_kernel<GT, VARIANT, DO_STEP>), dim3((unsigned)blocks), dim3(LMAZE_BLOCK),
-                           shared_lds_bytes(a.grid, GT != 0), s, a);
-    } else {
-        StepArgs b = a;
-        b.envs_per_block = perenv_envs_per_block(a.grid);
-        const int64_t blocks = (a.n + b.envs_per_block - 1) / b.envs_per_block;
-        hipLaunchKernelGGL((step_perenv_kernel<GT, VARIANT, DO_STEP>), dim3((unsigned)blocks), dim3(LMAZE_BLOCK),
-                           perenv_lds_bytes(a.grid, b.envs_per_block), s, b);
+    if (layout_mode != LMAZE_LAYOUT_SHARED) return launch_perenv<GT, VARIANT, DO_STEP>(a, s);
+    if constexpr (GT == 8) {
+        return launch_shared<GT, VARIANT, DO_STEP, 128>(a, s);
+    } else if constexpr (GT == 11 || GT == 12) {
+        return launch_shared<GT, VARIANT, DO_STEP, 64>(a, s);
+    } else if constexpr (GT == 14 || GT == 18) {
+        return launch_shared<GT, VARIANT, DO_STEP, 32>(a, s);
+    } else if constexpr (GT == 32) {
+        return launch_shared<GT, VARIANT, DO_STEP, 8>(a, s);
+    } else {  // unspecialised G: three sizes cover [3, 64]
+        if (a.grid >= 23) return launch_shared<GT, VARIANT, DO_STEP, 16>(a, s);
+        if (a.grid >= 12) return launch_shared<GT, VARIANT, DO_STEP, 64>(a, s);
+        return launch_shared<GT, VARIANT, DO_STEP, 256>(a, s);
     }
-    return hipGetLastError();
 }
 
 // Grid sizes the kernels are specialised for: the reference's shipped sizes (12, 14, 18)
