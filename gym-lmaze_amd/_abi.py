@@ -19,7 +19,8 @@ MAX_GRID, MAX_CHANNELS = 64, 8
 # every symbol include/lmaze.h declares (tests/test_abi_symbols.py parses the header and
 # checks this list and the loaded library against it)
 SYMBOLS = ("lmaze_abi_version", "lmaze_strerror", "lmaze_device_info", "lmaze_step_v0", "lmaze_step_v3",
-           "lmaze_observe", "lmaze_reset", "lmaze_render_expanded")
+           "lmaze_step_v0_autoreset", "lmaze_step_v3_autoreset", "lmaze_observe", "lmaze_reset",
+           "lmaze_render_expanded")
 
 
 class LmazeParams(C.Structure):
@@ -53,6 +54,10 @@ def _load():
     lib.lmaze_step_v0.argtypes = [P, vp, vp, vp, vp, vp, vp, vp, vp, i64, vp]
     lib.lmaze_step_v3.restype = C.c_int
     lib.lmaze_step_v3.argtypes = [P, vp, vp, vp, vp, vp, vp, vp, vp, i64, vp]
+    lib.lmaze_step_v0_autoreset.restype = C.c_int
+    lib.lmaze_step_v0_autoreset.argtypes = [P, vp, vp, vp, vp, vp, vp, vp, vp, i64, u64, u64, i64, vp]
+    lib.lmaze_step_v3_autoreset.restype = C.c_int
+    lib.lmaze_step_v3_autoreset.argtypes = [P, vp, vp, vp, vp, vp, vp, vp, vp, i64, u64, u64, i64, vp]
     lib.lmaze_observe.restype = C.c_int
     lib.lmaze_observe.argtypes = [P, vp, vp, vp, vp, i64, vp]
     lib.lmaze_reset.restype = C.c_int

@@ -38,6 +38,12 @@ static StepArgs make_args(const LmazeParams* p, const uint8_t* layout, const int
     a.reward_move = p->reward_move;
     a.reward_goal = p->reward_goal;
     a.envs_per_block = 0;
+    a.auto_reset = 0;
+    a.seed = 0;
+    a.epoch = 0;
+    a.env_base = 0;
+    a.goal_rw = nullptr;
+    a.mask = nullptr;
     return a;
 }
 
@@ -101,6 +107,42 @@ int lmaze_step_v3(const LmazeParams* params, const uint8_t* layout, const int32_
     return (int)launch_step(LMAZE_VARIANT_V3, true, a, params->layout_mode, (hipStream_t)stream);
 }
 
+int lmaze_step_v0_autoreset(const LmazeParams* params, const uint8_t* layout, const int32_t* action,
+                            int32_t* ball_xy, int32_t* step_count, float* reward, uint8_t* done,
+                            int32_t* goal_count, int32_t* obs, int64_t n, uint64_t seed, uint64_t epoch,
+                            int64_t env_base, void* stream) {
+    int rc = check_params(params, n);
+    if (rc) return rc;
+    if (params->variant != LMAZE_VARIANT_V0) return LMAZE_E_VARIANT;
+    if (!layout || !action || !ball_xy || !step_count || !reward || !done) return LMAZE_E_NULL;
+    if (misaligned(ball_xy, 8) || misaligned(obs, 16) || misaligned(layout, 16)) return LMAZE_E_ALIGN;
+    StepArgs a = make_args(params, layout, action, ball_xy, nullptr, step_count, reward, done, goal_count, obs, n);
+    a.auto_reset = 1;
+    a.seed = seed;
+    a.epoch = epoch;
+    a.env_base = env_base;
+    return (int)launch_step(LMAZE_VARIANT_V0, true, a, params->layout_mode, (hipStream_t)stream);
+}
+
+int lmaze_step_v3_autoreset(const LmazeParams* params, const uint8_t* layout, const int32_t* action,
+                            int32_t* ball_xy, int32_t* goal_xy, int32_t* step_count, float* reward,
+                            uint8_t* done, int32_t* obs, int64_t n, uint64_t seed, uint64_t epoch,
+                            int64_t env_base, void* stream) {
+    int rc = check_params(params, n);
+    if (rc) return rc;
+    if (params->variant != LMAZE_VARIANT_V3) return LMAZE_E_VARIANT;
+    if (!layout || !action || !ball_xy || !goal_xy || !step_count || !reward || !done) return LMAZE_E_NULL;
+    if (misaligned(ball_xy, 8) || misaligned(goal_xy, 8) || misaligned(obs, 16) || misaligned(layout, 16))
+        return LMAZE_E_ALIGN;
+    StepArgs a = make_args(params, layout, action, ball_xy, goal_xy, step_count, reward, done, nullptr, obs, n);
+    a.auto_reset = 1;
+    a.seed = seed;
+    a.epoch = epoch;
+    a.env_base = env_base;
+    a.goal_rw = reinterpret_cast<int2*>(goal_xy);
+    return (int)launch_step(LMAZE_VARIANT_V3, true, a, params->layout_mode, (hipStream_t)stream);
+}
+
 int lmaze_observe(const LmazeParams* params, const uint8_t* layout, const int32_t* ball_xy,
                   const int32_t* goal_xy, int32_t* obs, int64_t n, void* stream) {
     int rc = check_params(params, n);
@@ -141,6 +183,7 @@ int lmaze_reset(const LmazeParams* params, const uint8_t* layout, const uint8_t*
     hipError_t e = launch_reset(params->variant, r, params->layout_mode, (hipStream_t)stream);
     if (e != hipSuccess || !obs) return (int)e;
     StepArgs a = make_args(params, layout, nullptr, ball_xy, goal_xy, nullptr, nullptr, nullptr, nullptr, obs, n);
+    a.mask = mask;  // only the envs that were reset are re-rendered
     return (int)launch_step(params->variant, false, a, params->layout_mode, (hipStream_t)stream);
 }
 

@@ -6,38 +6,6 @@
 namespace lmaze {
 
 
-// Philox4x32-10 (Salmon, Moraes, Dror, Shaw: "Parallel random numbers: as easy as 1, 2, 3", SC'11)
-__device__ __forceinline__ uint4 philox4x32_10(uint4 c, uint2 k) {
-#pragma unroll
-    for (int r = 0; r < 10; ++r) {
-        const uint32_t hi0 = __umulhi(0xD2511F53u, c.x), lo0 = 0xD2511F53u * c.x;
-        const uint32_t hi1 = __umulhi(0xCD9E8D57u, c.z), lo1 = 0xCD9E8D57u * c.z;
-        c = make_uint4(hi1 ^ c.y ^ k.x, lo1, hi0 ^ c.w ^ k.y, lo0);
-        k.x += 0x9E3779B9u;
-        k.y += 0xBB67AE85u;
-    }
-    return c;
-}
-
-__device__ __forceinline__ uint4 env_draw(const ResetArgs& a, int64_t local) {
-    const uint64_t e = (uint64_t)(a.env_base + local);
-    return philox4x32_10(make_uint4((uint32_t)e, (uint32_t)(e >> 32), (uint32_t)a.epoch,
-                                    (uint32_t)(a.epoch >> 32)),
-                         make_uint2((uint32_t)a.seed, (uint32_t)(a.seed >> 32)));
-}
-
-// cells the reference's rejection loops accept.  v0:73 ball: not 'W', not 'X'.
-// v3:149 goal: not 'W' (the ball list is the same list minus the goal cell, v3:158).
-template <int VARIANT>
-__device__ __forceinline__ bool spawn_ok(uint8_t c) {
-    return VARIANT == LMAZE_VARIANT_V3 ? (c != 'W') : (c != 'W' && c != 'X');
-}
-
-__device__ __forceinline__ bool interior(int cell, int G) {
-    const int x = cell / G, y = cell - x * G;
-    return x >= 1 && x <= G - 2 && y >= 1 && y <= G - 2;
-}
-
 __device__ __forceinline__ void write_reset(const ResetArgs& a, int64_t e) {
     a.step_count[e] = 0;  // v0:110
     a.reward[e] = -0.0f;  // v0:109
@@ -54,56 +22,18 @@ __global__ __launch_bounds__(LMAZE_BLOCK) void reset_shared_kernel(const ResetAr
     const int G = a.grid, CELLS = G * G;
     const int tid = threadIdx.x;
     if (tid < 64) {
-        int count = 0;
-        for (int base = 0; base < CELLS; base += 64) {
-            const int cell = base + tid;
-            const bool ok = cell < CELLS && interior(cell, G) && spawn_ok<VARIANT>(a.layout[cell]);
-            const unsigned long long m = __ballot(ok);
-            if (ok) list[count + __popcll(m & ((1ull << tid) - 1ull))] = (uint16_t)cell;
-            count += __popcll(m);
-        }
+        const int count = wave_build_spawn_list<VARIANT>(a.layout, G, CELLS, list, tid);
         if (tid == 0) count_s = count;
     }
     __syncthreads();
     const int64_t e = (int64_t)blockIdx.x * LMAZE_BLOCK + tid;
     if (e >= a.n) return;
     if (a.mask && !a.mask[e]) return;
-    const int count = count_s;
-    const uint4 r = env_draw(a, e);
-    if (VARIANT == LMAZE_VARIANT_V3) {
-        int kg = -1;
-        if (count > 0) {
-            kg = (int)__umulhi(r.x, (uint32_t)count);
-            const int cell = list[kg];
-            a.goal[e] = make_int2(cell / G, cell % G);
-        }
-        if (count > 1) {
-            int kb = (int)__umulhi(r.y, (uint32_t)(count - 1));
-            kb += (kb >= kg);
-            const int cell = list[kb];
-            a.ball[e] = make_int2(cell / G, cell % G);
-        }
-    } else if (count > 0) {
-        const int cell = list[__umulhi(r.y, (uint32_t)count)];
-        a.ball[e] = make_int2(cell / G, cell % G);
-    }
+    int ball_cell, goal_cell;
+    place_from_list<VARIANT>(list, count_s, env_draw(a.seed, a.epoch, a.env_base + e), ball_cell, goal_cell);
+    if (goal_cell >= 0) a.goal[e] = make_int2(goal_cell / G, goal_cell % G);
+    if (ball_cell >= 0) a.ball[e] = make_int2(ball_cell / G, ball_cell % G);
     write_reset(a, e);
-}
-
-// k-th accepted cell of one env's own layout, found by a whole wave (all lanes call this)
-template <int VARIANT>
-__device__ __forceinline__ int wave_kth_cell(const uint8_t* lay, int G, int CELLS, int k, int lane) {
-    int seen = 0, found = -1;
-    for (int base = 0; base < CELLS; base += 64) {
-        const int cell = base + lane;
-        const bool ok = cell < CELLS && interior(cell, G) && spawn_ok<VARIANT>(lay[cell]);
-        const unsigned long long m = __ballot(ok);
-        const int rank = seen + __popcll(m & ((1ull << lane) - 1ull));
-        const unsigned long long hit = __ballot(ok && rank == k);
-        if (hit) found = base + __ffsll((long long)hit) - 1;
-        seen += __popcll(m);
-    }
-    return found;
 }
 
 // Per-env layouts: one wave per env scans that env's G*G bytes (coalesced) with ballots.
@@ -114,32 +44,14 @@ __global__ __launch_bounds__(LMAZE_BLOCK) void reset_perenv_kernel(const ResetAr
     const int64_t e = (int64_t)blockIdx.x * (LMAZE_BLOCK / 64) + (threadIdx.x >> 6);
     if (e >= a.n) return;
     if (a.mask && !a.mask[e]) return;
-    const uint8_t* lay = a.layout + (size_t)e * CELLS;
-    int count = 0;
-    for (int base = 0; base < CELLS; base += 64) {
-        const int cell = base + lane;
-        const bool ok = cell < CELLS && interior(cell, G) && spawn_ok<VARIANT>(lay[cell]);
-        count += __popcll(__ballot(ok));
+    int ball_cell, goal_cell;
+    wave_place<VARIANT>(a.layout + (size_t)e * CELLS, G, CELLS, env_draw(a.seed, a.epoch, a.env_base + e), lane,
+                        ball_cell, goal_cell);
+    if (lane == 0) {
+        if (goal_cell >= 0) a.goal[e] = make_int2(goal_cell / G, goal_cell % G);
+        if (ball_cell >= 0) a.ball[e] = make_int2(ball_cell / G, ball_cell % G);
+        write_reset(a, e);
     }
-    const uint4 r = env_draw(a, e);
-    if (VARIANT == LMAZE_VARIANT_V3) {
-        int kg = -1;
-        if (count > 0) {
-            kg = (int)__umulhi(r.x, (uint32_t)count);
-            const int cell = wave_kth_cell<VARIANT>(lay, G, CELLS, kg, lane);
-            if (lane == 0) a.goal[e] = make_int2(cell / G, cell % G);
-        }
-        if (count > 1) {
-            int kb = (int)__umulhi(r.y, (uint32_t)(count - 1));
-            kb += (kb >= kg);
-            const int cell = wave_kth_cell<VARIANT>(lay, G, CELLS, kb, lane);
-            if (lane == 0) a.ball[e] = make_int2(cell / G, cell % G);
-        }
-    } else if (count > 0) {
-        const int cell = wave_kth_cell<VARIANT>(lay, G, CELLS, (int)__umulhi(r.y, (uint32_t)count), lane);
-        if (lane == 0) a.ball[e] = make_int2(cell / G, cell % G);
-    }
-    if (lane == 0) write_reset(a, e);
 }
 
 hipError_t launch_reset(int variant, const ResetArgs& a, int layout_mode, hipStream_t s) {

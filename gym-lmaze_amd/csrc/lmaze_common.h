@@ -27,6 +27,13 @@ struct StepArgs {
     int32_t step_limit;
     float reward_wall, reward_move, reward_goal;
     int32_t envs_per_block;  // per-env-layout kernels: envs whose layouts one workgroup tiles in LDS
+    // fused auto-reset (lmaze_step_*_autoreset): an env whose done flag is set on entry is
+    // re-placed exactly as lmaze_reset(mask = done, seed, epoch, env_base) would, then stepped
+    int32_t auto_reset;
+    uint64_t seed, epoch;
+    int64_t env_base;
+    int2* goal_rw;           // v3 + auto_reset: the goal array, writable
+    const uint8_t* mask;     // observe only: re-render just the envs with mask != 0 (null = all)
 };
 
 // masked on-device reset (lmaze_aux.hip)
@@ -81,9 +88,9 @@ __device__ __forceinline__ int clampi(int v, int lo, int hi) { return v < lo ? l
 // raise IndexError or wrap); indices are clamped only so a bad input cannot fault the GPU.
 template <int VARIANT>
 __device__ __forceinline__ void transition(const StepArgs& a, const uint8_t* lay, int G, int64_t e,
-                                           int& bx, int& by, int gx, int gy) {
+                                           int sc_in, float r_in, int& bx, int& by, int gx, int gy) {
     const int act = a.action[e];
-    const int sc = a.step_count[e] + 1;  // v0:151, v3:225
+    const int sc = sc_in + 1;  // v0:151, v3:225
     int ox, oy;
     decode_action(act, ox, oy);
     const int tx = clampi(bx + ox, 0, G - 1), ty = clampi(by + oy, 0, G - 1);
@@ -100,7 +107,7 @@ __device__ __forceinline__ void transition(const StepArgs& a, const uint8_t* lay
         }
         dn = (r == a.reward_goal) || (sc > a.step_limit);  // v3:398
     } else {
-        r = a.reward[e];  // sticky: no else branch in v0:172-195
+        r = r_in;  // sticky: no else branch in v0:172-195
         if (c == 'W') {
             r = a.reward_wall;  // v0:174
         } else if (c == 'B') {
@@ -119,46 +126,124 @@ __device__ __forceinline__ void transition(const StepArgs& a, const uint8_t* lay
     a.done[e] = dn ? 1 : 0;
 }
 
-// The same transition read off the LDS pattern of static plane bits instead of the layout
-// characters: WALL <=> 'W'; v0 FREE <=> 'B', GOAL <=> 'X', none <=> 'S' (no branch fires).
-template <int VARIANT>
-__device__ __forceinline__ void transition_bits(const StepArgs& a, const int* pat, int G, int64_t e,
-                                                int& bx, int& by, int gx, int gy) {
-    const int act = a.action[e];
-    const int sc = a.step_count[e] + 1;  // v0:151, v3:225
-    int ox, oy;
-    decode_action(act, ox, oy);
-    const int tx = clampi(bx + ox, 0, G - 1), ty = clampi(by + oy, 0, G - 1);
-    const int cb = pat[tx * G + ty];  // v0:172, v3:251
-    float r;
-    bool dn;
-    if (VARIANT == LMAZE_VARIANT_V3) {
-        r = -0.0f;  // v3:224
-        if (cb & LMAZE_OBS_WALL) {
-            r = a.reward_wall;  // v3:252
-        } else {
-            bx = tx; by = ty;   // v3:258-259
-            r = (bx + ox == gx && by + oy == gy) ? a.reward_goal : a.reward_move;  // v3:262-265
-        }
-        dn = (r == a.reward_goal) || (sc > a.step_limit);  // v3:398
-    } else {
-        r = a.reward[e];  // sticky: no else branch in v0:172-195
-        if (cb & LMAZE_OBS_WALL) {
-            r = a.reward_wall;  // v0:174
-        } else if (cb & LMAZE_OBS_FREE) {
-            bx = tx; by = ty;   // v0:180-181
-            r = a.reward_move;  // v0:184
-        } else if (cb & LMAZE_OBS_GOAL) {
-            bx = tx; by = ty;   // v0:190-191
-            r = a.reward_goal;  // v0:194
-            if (a.goal_count) a.goal_count[e] += 1;  // v0:195
-        }
-        dn = (r == a.reward_goal) || (sc == a.step_limit);  // v0:246-249
+// Philox4x32-10 (Salmon, Moraes, Dror, Shaw: "Parallel random numbers: as easy as 1, 2, 3", SC'11)
+__device__ __forceinline__ uint4 philox4x32_10(uint4 c, uint2 k) {
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        const uint32_t hi0 = __umulhi(0xD2511F53u, c.x), lo0 = 0xD2511F53u * c.x;
+        const uint32_t hi1 = __umulhi(0xCD9E8D57u, c.z), lo1 = 0xCD9E8D57u * c.z;
+        c = make_uint4(hi1 ^ c.y ^ k.x, lo1, hi0 ^ c.w ^ k.y, lo0);
+        k.x += 0x9E3779B9u;
+        k.y += 0xBB67AE85u;
     }
-    a.ball[e] = make_int2(bx, by);
-    a.step_count[e] = sc;
-    a.reward[e] = r;
-    a.done[e] = dn ? 1 : 0;
+    return c;
+}
+
+// the reset draw of one env: counter = (global env index, epoch), key = seed
+__device__ __forceinline__ uint4 env_draw(uint64_t seed, uint64_t epoch, int64_t env_global) {
+    const uint64_t e = (uint64_t)env_global;
+    return philox4x32_10(make_uint4((uint32_t)e, (uint32_t)(e >> 32), (uint32_t)epoch, (uint32_t)(epoch >> 32)),
+                         make_uint2((uint32_t)seed, (uint32_t)(seed >> 32)));
+}
+
+// cells the reference's rejection loops accept.  v0:73 ball: not 'W', not 'X'.
+// v3:149 goal: not 'W' (the ball list is the same list minus the goal cell, v3:158).
+template <int VARIANT>
+__device__ __forceinline__ bool spawn_ok(uint8_t c) {
+    return VARIANT == LMAZE_VARIANT_V3 ? (c != 'W') : (c != 'W' && c != 'X');
+}
+
+__device__ __forceinline__ bool interior(int cell, int G) {
+    const int x = cell / G, y = cell - x * G;
+    return x >= 1 && x <= G - 2 && y >= 1 && y <= G - 2;
+}
+
+// One wave compacts the accepted cells of `lay` (row-major) into list[]; returns the count
+// (valid in every lane).  All 64 lanes of the wave must call it.
+template <int VARIANT>
+__device__ __forceinline__ int wave_build_spawn_list(const uint8_t* lay, int G, int CELLS, uint16_t* list, int lane) {
+    int count = 0;
+    for (int base = 0; base < CELLS; base += 64) {
+        const int cell = base + lane;
+        const bool ok = cell < CELLS && interior(cell, G) && spawn_ok<VARIANT>(lay[cell]);
+        const unsigned long long m = __ballot(ok);
+        if (ok) list[count + __popcll(m & ((1ull << lane) - 1ull))] = (uint16_t)cell;
+        count += __popcll(m);
+    }
+    return count;
+}
+
+// placement from a compacted list: goal = list[(r.x*count)>>32]; ball = the (r.y*(count-1))>>32-th
+// entry skipping the goal (v3) or list[(r.y*count)>>32] (v0).  Cells < 0 mean "leave unchanged".
+template <int VARIANT>
+__device__ __forceinline__ void place_from_list(const uint16_t* list, int count, uint4 r, int& ball_cell, int& goal_cell) {
+    ball_cell = -1;
+    goal_cell = -1;
+    if (VARIANT == LMAZE_VARIANT_V3) {
+        int kg = -1;
+        if (count > 0) {
+            kg = (int)__umulhi(r.x, (uint32_t)count);
+            goal_cell = list[kg];
+        }
+        if (count > 1) {
+            int kb = (int)__umulhi(r.y, (uint32_t)(count - 1));
+            kb += (kb >= kg);
+            ball_cell = list[kb];
+        }
+    } else if (count > 0) {
+        ball_cell = list[__umulhi(r.y, (uint32_t)count)];
+    }
+}
+
+// k-th accepted cell (row-major, 0-based) of one layout, found by a whole wave with ballots;
+// every lane returns the same cell (-1 if there are fewer than k+1)
+template <int VARIANT>
+__device__ __forceinline__ int wave_kth_cell(const uint8_t* lay, int G, int CELLS, int k, int lane) {
+    int seen = 0, found = -1;
+    for (int base = 0; base < CELLS; base += 64) {
+        const int cell = base + lane;
+        const bool ok = cell < CELLS && interior(cell, G) && spawn_ok<VARIANT>(lay[cell]);
+        const unsigned long long m = __ballot(ok);
+        const int rank = seen + __popcll(m & ((1ull << lane) - 1ull));
+        const unsigned long long hit = __ballot(ok && rank == k);
+        if (hit) found = base + __ffsll((long long)hit) - 1;
+        seen += __popcll(m);
+    }
+    return found;
+}
+
+template <int VARIANT>
+__device__ __forceinline__ int wave_count_cells(const uint8_t* lay, int G, int CELLS, int lane) {
+    int count = 0;
+    for (int base = 0; base < CELLS; base += 64) {
+        const int cell = base + lane;
+        const bool ok = cell < CELLS && interior(cell, G) && spawn_ok<VARIANT>(lay[cell]);
+        count += __popcll(__ballot(ok));
+    }
+    return count;
+}
+
+// whole-wave placement on one env's own layout (HBM or LDS): same rule as place_from_list
+template <int VARIANT>
+__device__ __forceinline__ void wave_place(const uint8_t* lay, int G, int CELLS, uint4 r, int lane,
+                                           int& ball_cell, int& goal_cell) {
+    ball_cell = -1;
+    goal_cell = -1;
+    const int count = wave_count_cells<VARIANT>(lay, G, CELLS, lane);
+    if (VARIANT == LMAZE_VARIANT_V3) {
+        int kg = -1;
+        if (count > 0) {
+            kg = (int)__umulhi(r.x, (uint32_t)count);
+            goal_cell = wave_kth_cell<VARIANT>(lay, G, CELLS, kg, lane);
+        }
+        if (count > 1) {
+            int kb = (int)__umulhi(r.y, (uint32_t)(count - 1));
+            kb += (kb >= kg);
+            ball_cell = wave_kth_cell<VARIANT>(lay, G, CELLS, kb, lane);
+        }
+    } else if (count > 0) {
+        ball_cell = wave_kth_cell<VARIANT>(lay, G, CELLS, (int)__umulhi(r.y, (uint32_t)count), lane);
+    }
 }
 
 // OR `bit` into component d (0..3) of v; other d leave v unchanged

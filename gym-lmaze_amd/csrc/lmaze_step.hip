@@ -4,7 +4,7 @@
 // lmaze_env_v3.py:220-402): action decode, wall-collision check, position update,
 // reward/done, and the full re-render of the observation planes.
 //
-// Shape of the work (DESIGN.md "Kernels"): per env 37 B of state traffic and 4*G*G B of
+// Shape of the work: per env 37 B of state traffic and 4*G*G B of
 // observation written -- an HBM-write-bound stream with integer indexing, no MFMA.
 //   phase 1  one lane per env: coalesced SoA loads, transition against the layout held in
 //            LDS, coalesced SoA stores; the new ball cell goes to LDS.
@@ -15,13 +15,14 @@
 //            store costs one ds_read_b128 + a few compares.  Per-env layouts: the
 //            workgroup's layouts are tiled into LDS first (one coalesced read), and both
 //            the collision check and the render read them from there.
+// Options folded into the same kernels (wave-uniform branches, no extra traffic):
+//   auto_reset  an env whose done flag is set on entry is first re-placed exactly as
+//               lmaze_reset(mask = done) would (reference reset(), lmaze_env.py:64-110)
+//   mask        (observe only) re-render just the envs a masked reset touched
 #include "lmaze_common.h"
 
 namespace lmaze {
 
-// ------------------------------------------------------------------------------------
-// Shared layout.  GT = G known at compile time (0: read it from the args).
-// ------------------------------------------------------------------------------------
 template <bool NT>
 __device__ __forceinline__ void store16(int4* p, const int4& v) {
     typedef int v4i __attribute__((ext_vector_type(4)));
@@ -33,8 +34,43 @@ __device__ __forceinline__ void store16(int4* p, const int4& v) {
     }
 }
 
-// EPB = envs per workgroup (multiple of 4); NT = non-temporal obs stores
-template <int GT, int VARIANT, bool DO_STEP, int EPB = LMAZE_BLOCK, bool NT = false>
+// one env of phase 1; returns the env's ball (and goal) cell index for phase 2
+template <int VARIANT, bool DO_STEP>
+__device__ __forceinline__ void env_phase1(const StepArgs& a, const uint8_t* lay, int G, int64_t e,
+                                           const uint16_t* spawn, int spawn_count, int& ball_cell, int& goal_cell) {
+    constexpr bool V3 = VARIANT == LMAZE_VARIANT_V3;
+    int2 b = a.ball[e];
+    int2 g = make_int2(-1, -1);
+    if (V3) g = a.goal[e];
+    if (DO_STEP) {
+        int sc_in = a.step_count[e];
+        float r_in = V3 ? 0.0f : a.reward[e];
+        if (a.auto_reset && a.done[e]) {  // reference reset(): placement + zeroed counters
+            int bc, gc;
+            place_from_list<VARIANT>(spawn, spawn_count, env_draw(a.seed, a.epoch, a.env_base + e), bc, gc);
+            if (bc >= 0) b = make_int2(bc / G, bc % G);
+            if (V3 && gc >= 0) {
+                g = make_int2(gc / G, gc % G);
+                a.goal_rw[e] = g;
+            }
+            sc_in = 0;      // v0:110
+            r_in = -0.0f;   // v0:109
+        }
+        int bx = clampi(b.x, 0, G - 1), by = clampi(b.y, 0, G - 1);
+        transition<VARIANT>(a, lay, G, e, sc_in, r_in, bx, by, g.x, g.y);
+        b = make_int2(bx, by);
+    } else {
+        b = make_int2(clampi(b.x, 0, G - 1), clampi(b.y, 0, G - 1));
+    }
+    ball_cell = b.x * G + b.y;
+    goal_cell = (V3 && g.x >= 0 && g.x < G && g.y >= 0 && g.y < G) ? g.x * G + g.y : -8;
+}
+
+// ------------------------------------------------------------------------------------
+// Shared layout.  GT = G known at compile time (0: read it from the args);
+// EPB = envs per workgroup (multiple of 4); NT = non-temporal obs stores.
+// ------------------------------------------------------------------------------------
+template <int GT, int VARIANT, bool DO_STEP, int EPB, bool NT>
 __global__ __launch_bounds__(LMAZE_BLOCK) void step_shared_kernel(const StepArgs a) {
     constexpr bool V3 = VARIANT == LMAZE_VARIANT_V3;
     static_assert(EPB % 4 == 0, "group alignment");
@@ -49,34 +85,42 @@ __global__ __launch_bounds__(LMAZE_BLOCK) void step_shared_kernel(const StepArgs
     int* pat = reinterpret_cast<int*>(lds4);
     int* ballflat = pat + PAT;
     int* goalflat = ballflat + EPB;
-    uint8_t* lay = reinterpret_cast<uint8_t*>(goalflat + EPB);
+    int* maskflag = goalflat + EPB;
+    uint8_t* lay = reinterpret_cast<uint8_t*>(maskflag + EPB);
+    uint16_t* spawn = reinterpret_cast<uint16_t*>(lay + ((CELLS + 15) & ~15));
+    __shared__ int spawn_count_s;
 
     const int tid = threadIdx.x;
     const int64_t blockbase = (int64_t)blockIdx.x * EPB;
     const int nb = (int)min((int64_t)EPB, a.n - blockbase);  // envs in this workgroup
+    const bool masked = !DO_STEP && a.mask != nullptr;
+    const bool autoreset = DO_STEP && a.auto_reset;
 
     for (int i = tid; i < CELLS; i += LMAZE_BLOCK) lay[i] = a.layout[i];
     for (int i = tid; i < PAT; i += LMAZE_BLOCK) {
         const int c = (GT != 0 && GRP > 1) ? i % CELLS : i;
         pat[i] = cell_bits<VARIANT>(a.layout[c]);
     }
+    if (autoreset && tid < 64) {
+        const int cnt = wave_build_spawn_list<VARIANT>(a.layout, G, CELLS, spawn, tid);
+        if (tid == 0) spawn_count_s = cnt;
+    }
     __syncthreads();
 
-    for (int le = tid; le < EPB; le += LMAZE_BLOCK) {  // one lane per env (EPB <= block: one pass)
+    for (int le = tid; le < EPB; le += LMAZE_BLOCK) {  // one lane per env
+        int bf = -8, gf = -8, mf = 0;
         if (le < nb) {
             const int64_t e = blockbase + le;
-            const int2 b = a.ball[e];
-            int2 g = make_int2(-1, -1);
-            if (V3) g = a.goal[e];
-            int bx = clampi(b.x, 0, G - 1), by = clampi(b.y, 0, G - 1);
-            if (DO_STEP) transition<VARIANT>(a, lay, G, e, bx, by, g.x, g.y);
+            int bc, gc;
+            env_phase1<VARIANT, DO_STEP>(a, lay, G, e, spawn, autoreset ? spawn_count_s : 0, bc, gc);
             const int off = (GT != 0) ? (le % GRP) * CELLS : 0;
-            ballflat[le] = off + bx * G + by;
-            if (V3) goalflat[le] = (g.x >= 0 && g.x < G && g.y >= 0 && g.y < G) ? off + g.x * G + g.y : -8;
-        } else {
-            ballflat[le] = -8;
-            if (V3) goalflat[le] = -8;
+            bf = off + bc;
+            if (V3 && gc >= 0) gf = off + gc;
+            if (masked) mf = a.mask[e] != 0;
         }
+        ballflat[le] = bf;
+        if (V3) goalflat[le] = gf;
+        if (masked) maskflag[le] = mf;
     }
     if (a.obs == nullptr) return;
     __syncthreads();
@@ -95,6 +139,10 @@ __global__ __launch_bounds__(LMAZE_BLOCK) void step_shared_kernel(const StepArgs
             int4 v = pat4[p];
             const int p4 = p << 2;
             if (GRP == 4) {
+                if (masked) {
+                    const int4 m = reinterpret_cast<const int4*>(maskflag)[grp];
+                    if (!(m.x | m.y | m.z | m.w)) continue;
+                }
                 const int4 bf = reinterpret_cast<const int4*>(ballflat)[grp];
                 or_at(v, bf.x - p4, LMAZE_OBS_BALL);
                 or_at(v, bf.y - p4, LMAZE_OBS_BALL);
@@ -108,6 +156,7 @@ __global__ __launch_bounds__(LMAZE_BLOCK) void step_shared_kernel(const StepArgs
                     or_at(v, gf.w - p4, LMAZE_OBS_GOAL);
                 }
             } else {
+                if (masked && !maskflag[grp]) continue;
                 or_at(v, ballflat[grp] - p4, LMAZE_OBS_BALL);
                 if (V3) or_at(v, goalflat[grp] - p4, LMAZE_OBS_GOAL);
             }
@@ -118,6 +167,10 @@ __global__ __launch_bounds__(LMAZE_BLOCK) void step_shared_kernel(const StepArgs
             const int f0 = q << 2;
             int le = f0 / CELLS;
             int c = f0 - le * CELLS;
+            if (masked) {  // the store may straddle two envs
+                const int le1 = (f0 + 3) / CELLS;
+                if (!(maskflag[le] | maskflag[le1 < EPB ? le1 : le])) continue;
+            }
             int vals[4];
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
@@ -139,7 +192,7 @@ __global__ __launch_bounds__(LMAZE_BLOCK) void step_shared_kernel(const StepArgs
         int v = pat[(GT != 0 && GRP > 1) ? off + c : c];
         v |= (ballflat[le] == off + c) ? LMAZE_OBS_BALL : 0;
         if (V3) v |= (goalflat[le] == off + c) ? LMAZE_OBS_GOAL : 0;
-        obs[f] = v;
+        if (!masked || maskflag[le]) obs[f] = v;
     }
 }
 
@@ -158,20 +211,25 @@ __global__ __launch_bounds__(LMAZE_BLOCK) void step_perenv_kernel(const StepArgs
     const int tile_bytes = (EPB * CELLS + 15) & ~15;
     int* ballcell = reinterpret_cast<int*>(tile + tile_bytes);  // [EPB+1]
     int* goalcell = ballcell + EPB + 1;                         // [EPB+1]
+    int* flag = goalcell + EPB + 1;                             // [EPB+1] done-on-entry / observe mask
+    int* newball = flag + EPB + 1;                              // [EPB]   auto-reset placement
+    int* newgoal = newball + EPB;                               // [EPB]
 
     const int tid = threadIdx.x;
     const int64_t blockbase = (int64_t)blockIdx.x * EPB;
     const int nb = (int)min((int64_t)EPB, a.n - blockbase);
-    const int64_t e = blockbase + tid;
-    const bool live = tid < nb;
     const int R = nb * CELLS;  // layout bytes read == obs dwords written by this workgroup
+    const bool autoreset = DO_STEP && a.auto_reset;
+    const bool masked = !DO_STEP && a.mask != nullptr;
 
-    int2 b = make_int2(0, 0), g = make_int2(-1, -1);
-    if (live) {
-        b = a.ball[e];
-        if (V3) g = a.goal[e];
+    if (tid <= EPB) {
+        int f = 0;
+        if (tid < nb) {
+            if (autoreset) f = a.done[blockbase + tid] != 0;
+            if (masked) f = a.mask[blockbase + tid] != 0;
+        }
+        flag[tid] = f;
     }
-
     // stage the layouts: 16 B per lane per instruction, ragged byte tail
     const uint8_t* src = a.layout + (size_t)blockbase * CELLS;
     const int n16 = R >> 4;
@@ -179,16 +237,50 @@ __global__ __launch_bounds__(LMAZE_BLOCK) void step_perenv_kernel(const StepArgs
     for (int i = (n16 << 4) + tid; i < R; i += LMAZE_BLOCK) tile[i] = src[i];
     __syncthreads();
 
-    if (tid <= EPB) {
-        if (live) {
-            int bx = clampi(b.x, 0, G - 1), by = clampi(b.y, 0, G - 1);
-            if (DO_STEP) transition<VARIANT>(a, tile + tid * CELLS, G, e, bx, by, g.x, g.y);
-            ballcell[tid] = bx * G + by;
-            if (V3) goalcell[tid] = (g.x >= 0 && g.x < G && g.y >= 0 && g.y < G) ? g.x * G + g.y : -8;
-        } else {
-            ballcell[tid] = -8;
-            if (V3) goalcell[tid] = -8;
+    if (autoreset) {
+        // wave w re-places the done envs w, w+4, ... of the workgroup with ballot scans of their tiles
+        const int lane = tid & 63;
+        for (int le = tid >> 6; le < nb; le += LMAZE_BLOCK / 64) {
+            if (!flag[le]) continue;
+            int bc, gc;
+            wave_place<VARIANT>(tile + le * CELLS, G, CELLS, env_draw(a.seed, a.epoch, a.env_base + blockbase + le), lane,
+                                bc, gc);
+            if (lane == 0) { newball[le] = bc; newgoal[le] = gc; }
         }
+        __syncthreads();
+    }
+
+    if (tid <= EPB) {
+        int bcell = -8, gcell = -8;
+        if (tid < nb) {
+            const int64_t e = blockbase + tid;
+            int2 b = a.ball[e];
+            int2 g = make_int2(-1, -1);
+            if (V3) g = a.goal[e];
+            if (DO_STEP) {
+                int sc_in = a.step_count[e];
+                float r_in = V3 ? 0.0f : a.reward[e];
+                if (autoreset && flag[tid]) {
+                    const int bc = newball[tid], gc = newgoal[tid];
+                    if (bc >= 0) b = make_int2(bc / G, bc % G);
+                    if (V3 && gc >= 0) {
+                        g = make_int2(gc / G, gc % G);
+                        a.goal_rw[e] = g;
+                    }
+                    sc_in = 0;
+                    r_in = -0.0f;
+                }
+                int bx = clampi(b.x, 0, G - 1), by = clampi(b.y, 0, G - 1);
+                transition<VARIANT>(a, tile + tid * CELLS, G, e, sc_in, r_in, bx, by, g.x, g.y);
+                b = make_int2(bx, by);
+            } else {
+                b = make_int2(clampi(b.x, 0, G - 1), clampi(b.y, 0, G - 1));
+            }
+            bcell = b.x * G + b.y;
+            if (V3 && g.x >= 0 && g.x < G && g.y >= 0 && g.y < G) gcell = g.x * G + g.y;
+        }
+        ballcell[tid] = bcell;
+        if (V3) goalcell[tid] = gcell;
     }
     if (a.obs == nullptr) return;
     __syncthreads();
@@ -205,6 +297,7 @@ __global__ __launch_bounds__(LMAZE_BLOCK) void step_perenv_kernel(const StepArgs
         int c = f0 - le * CELLS;
         int vals[4];
         if (whole) {
+            if (masked && !flag[le]) continue;
             const int bc = ballcell[le] - c;
             const int gc = V3 ? goalcell[le] - c : -8;
 #pragma unroll
@@ -215,6 +308,7 @@ __global__ __launch_bounds__(LMAZE_BLOCK) void step_perenv_kernel(const StepArgs
                 vals[j] = v;
             }
         } else {
+            if (masked && !(flag[le] | flag[(f0 + 3) / CELLS])) continue;
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 int v = cell_bits<VARIANT>((uint8_t)(w >> (8 * j)));
@@ -233,17 +327,18 @@ __global__ __launch_bounds__(LMAZE_BLOCK) void step_perenv_kernel(const StepArgs
         int v = cell_bits<VARIANT>(tile[f]);
         v |= (ballcell[le] == c) ? LMAZE_OBS_BALL : 0;
         if (V3) v |= (goalcell[le] == c) ? LMAZE_OBS_GOAL : 0;
-        obs[f] = v;
+        if (!masked || flag[le]) obs[f] = v;
     }
 }
 
 // ------------------------------------------------------------------------------------
 // host launchers
 // ------------------------------------------------------------------------------------
-static size_t shared_lds_bytes(int G, bool specialised, int epb = LMAZE_BLOCK) {
+static size_t shared_lds_bytes(int G, bool specialised, int epb) {
     const int cells = G * G;
     const int pat = (specialised && (G & 1)) ? 4 * cells : cells;
-    return (size_t)pat * 4 + 2 * (size_t)epb * 4 + (size_t)((cells + 15) & ~15);
+    // pattern + ballflat/goalflat/maskflag + layout bytes + spawn list (uint16 per cell)
+    return (size_t)pat * 4 + 3 * (size_t)epb * 4 + (size_t)((cells + 15) & ~15) + (size_t)((cells * 2 + 15) & ~15);
 }
 
 int perenv_envs_per_block(int G) {
@@ -255,7 +350,7 @@ int perenv_envs_per_block(int G) {
 }
 
 static size_t perenv_lds_bytes(int G, int epb) {
-    return (size_t)((epb * G * G + 15) & ~15) + 2 * (size_t)(epb + 1) * 4;
+    return (size_t)((epb * G * G + 15) & ~15) + (3 * (size_t)(epb + 1) + 2 * (size_t)epb) * 4;
 }
 
 // Obs buffers larger than this are written with non-temporal stores: they cannot stay in the

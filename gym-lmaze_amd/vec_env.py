@@ -94,7 +94,7 @@ class LmazeVecEnv(object):
             if validate:
                 L.validate(codes, need_goal_marker=not self._is_v3)
             self.layout_mode = _abi.LAYOUT_SHARED
-            self.layout = torch.from_numpy(codes).to(self.device)
+            self.layout = torch.from_numpy(codes.copy()).to(self.device)
         self.grid = int(self.layout.shape[-1])
         if not (3 <= self.grid <= _abi.MAX_GRID):
             raise ValueError("grid side must be in [3, %d]" % _abi.MAX_GRID)
@@ -173,36 +173,56 @@ class LmazeVecEnv(object):
         return a.contiguous()
 
     # ------------------------------------------------------------------ the hot path
-    def step(self, actions, render=True):
+    def step(self, actions, render=True, auto_reset=False):
         """One step() of every env.  Returns (obs, reward, done, actions): obs is the compact
         int32[N,G,G] plane buffer (rewritten in place every step), reward float32[N], done
-        bool[N].  render=False skips the observation write (transition only)."""
+        bool[N].  render=False skips the observation write (transition only).
+        auto_reset=True first resets the envs whose done flag is still set from the previous
+        step (the user loop `if done: env.reset()`), fused into the same kernel; the result is
+        bit-identical to `reset(mask=done)` followed by `step(actions)`."""
         a = self._as_actions(actions)
-        obs_ptr = self._p_obs if render else None
         with self._guard():
-            if self._is_v3:
-                rc = _abi.lib.lmaze_step_v3(self._pp, self._p_layout, a.data_ptr(), self._p_ball, self._p_goal,
-                                            self._p_step, self._p_reward, self._p_done, obs_ptr,
-                                            self.num_envs, self._stream())
-            else:
-                rc = _abi.lib.lmaze_step_v0(self._pp, self._p_layout, a.data_ptr(), self._p_ball, self._p_step,
-                                            self._p_reward, self._p_done, self._p_gc, obs_ptr,
-                                            self.num_envs, self._stream())
-        _abi.check("lmaze_step_" + self.variant, rc)
+            self._launch_step(a.data_ptr(), self._p_obs if render else None, auto_reset)
         return self.obs, self.reward, self.done, actions
 
-    def step_raw(self, action_ptr):
+    def step_raw(self, action_ptr, auto_reset=False):
         """step() on a raw device pointer to int32[N] actions (no tensor handling): for
         rollouts over a pre-generated [T,N] action tensor, e.g. under graph capture."""
-        if self._is_v3:
-            rc = _abi.lib.lmaze_step_v3(self._pp, self._p_layout, action_ptr, self._p_ball, self._p_goal,
-                                        self._p_step, self._p_reward, self._p_done, self._p_obs,
-                                        self.num_envs, self._stream())
+        self._launch_step(action_ptr, self._p_obs, auto_reset)
+
+    def _launch_step(self, action_ptr, obs_ptr, auto_reset):
+        lib, N, st = _abi.lib, self.num_envs, self._stream()
+        if auto_reset:
+            seed, epoch = self.seed & (2 ** 64 - 1), self._epoch
+            self._epoch += 1
+            if self._is_v3:
+                rc = lib.lmaze_step_v3_autoreset(self._pp, self._p_layout, action_ptr, self._p_ball, self._p_goal,
+                                                 self._p_step, self._p_reward, self._p_done, obs_ptr, N,
+                                                 seed, epoch, self.env_base, st)
+            else:
+                rc = lib.lmaze_step_v0_autoreset(self._pp, self._p_layout, action_ptr, self._p_ball, self._p_step,
+                                                 self._p_reward, self._p_done, self._p_gc, obs_ptr, N,
+                                                 seed, epoch, self.env_base, st)
+        elif self._is_v3:
+            rc = lib.lmaze_step_v3(self._pp, self._p_layout, action_ptr, self._p_ball, self._p_goal,
+                                   self._p_step, self._p_reward, self._p_done, obs_ptr, N, st)
         else:
-            rc = _abi.lib.lmaze_step_v0(self._pp, self._p_layout, action_ptr, self._p_ball, self._p_step,
-                                        self._p_reward, self._p_done, self._p_gc, self._p_obs,
-                                        self.num_envs, self._stream())
+            rc = lib.lmaze_step_v0(self._pp, self._p_layout, action_ptr, self._p_ball, self._p_step,
+                                   self._p_reward, self._p_done, self._p_gc, obs_ptr, N, st)
         _abi.check("lmaze_step_" + self.variant, rc)
+
+    def rollout(self, actions, auto_reset=True):
+        """T steps over a device tensor int32[T,N] of actions, one kernel per step, no host
+        sync (capture it into a hipGraph with torch.cuda.graph for launch-bound batch sizes).
+        Returns the final (obs, reward, done)."""
+        if not (isinstance(actions, torch.Tensor) and actions.dtype == torch.int32 and actions.dim() == 2
+                and actions.shape[1] == self.num_envs and actions.device == self.device and actions.is_contiguous()):
+            raise ValueError("rollout() wants a contiguous int32[T,N] tensor on %s" % (self.device,))
+        base, stride = actions.data_ptr(), self.num_envs * 4
+        with self._guard():
+            for t in range(actions.shape[0]):
+                self._launch_step(base + t * stride, self._p_obs, auto_reset)
+        return self.obs, self.reward, self.done
 
     def observe(self):
         """Re-render the compact planes of the current state (no transition)."""

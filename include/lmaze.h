@@ -134,12 +134,33 @@ int lmaze_observe(const LmazeParams* params, const uint8_t* layout, const int32_
  * epoch): env_base is the global index of this shard's env 0, so a batch sharded over
  * several GPUs draws exactly what one GPU holding the whole batch would.  The reference
  * draws from Python's global Mersenne Twister, so placement parity with it is
- * distributional, not bitwise.  obs (nullable) gets the reset planes.
+ * distributional, not bitwise.  obs (nullable): the planes of the envs that were reset are
+ * re-rendered (with a mask, envs outside it keep their current planes untouched).
  */
 int lmaze_reset(const LmazeParams* params, const uint8_t* layout, const uint8_t* mask,
                 uint64_t seed, uint64_t epoch, int64_t env_base, int32_t* ball_xy, int32_t* goal_xy,
                 int32_t* step_count, float* reward, uint8_t* done, int32_t* obs, int64_t n,
                 void* stream);
+
+/*
+ * step() with the reset fused in front of it, for rollouts longer than one episode: an env
+ * whose done[i] is set ON ENTRY (by the previous step) is first reset exactly as
+ * lmaze_reset(mask = done, seed, epoch, env_base) would -- new placement, step_count = 0,
+ * reward = -0.0 (v0:64-110, v3:134-167) -- and then takes this step's action, i.e. the
+ * user loop `if done: env.reset()` followed by `env.step(a)`, in one launch and with no
+ * extra HBM traffic.  Results are bit-identical to calling lmaze_reset then lmaze_step_*.
+ * The caller advances `epoch` every call so successive episodes draw fresh placements.
+ * goal_xy (v3) is read and, for reset envs, rewritten.
+ */
+int lmaze_step_v0_autoreset(const LmazeParams* params, const uint8_t* layout, const int32_t* action,
+                            int32_t* ball_xy, int32_t* step_count, float* reward, uint8_t* done,
+                            int32_t* goal_count, int32_t* obs, int64_t n, uint64_t seed,
+                            uint64_t epoch, int64_t env_base, void* stream);
+
+int lmaze_step_v3_autoreset(const LmazeParams* params, const uint8_t* layout, const int32_t* action,
+                            int32_t* ball_xy, int32_t* goal_xy, int32_t* step_count, float* reward,
+                            uint8_t* done, int32_t* obs, int64_t n, uint64_t seed, uint64_t epoch,
+                            int64_t env_base, void* stream);
 
 /*
  * Reference-layout observation: replaces the 5-deep upsample loop (v0:217-234,

@@ -334,6 +334,42 @@ def test_reset_placement_is_uniform_over_accepted_cells():
 
 
 # ----------------------------------------------------------------------------------------
+# 4b. fused auto-reset == reset(mask=done) then step, bit for bit (incl. the Philox epochs)
+# ----------------------------------------------------------------------------------------
+@pytest.mark.parametrize("variant", ["v0", "v3"])
+@pytest.mark.parametrize("shared,G", [(True, 11), (True, 12), (True, 9), (False, 8), (False, 11), (False, 32)])
+def test_fused_autoreset_equals_reset_then_step(variant, shared, G):
+    N, T, seed = 2500, 60, 21
+    kw = dict(variant=variant, seed=seed, step_limit=7, env_base=1000)   # short episodes: many resets
+    if shared:
+        lay = bordered_random_layouts(1, G, 300 + G)[0]
+        fused, split = PKG.LmazeVecEnv(N, layout=lay, **kw), PKG.LmazeVecEnv(N, layout=lay, **kw)
+    else:
+        lay = bordered_random_layouts(N, G, 300 + G)
+        fused, split = PKG.LmazeVecEnv(N, per_env_layouts=lay, **kw), PKG.LmazeVecEnv(N, per_env_layouts=lay, **kw)
+    rs = np.random.RandomState(G)
+    n_resets = 0
+    for t in range(T):
+        a = torch.from_numpy(rs.randint(0, 4, N).astype(np.int32))
+        n_resets += int(split.done.sum().item())
+        split.reset(mask=split.done)
+        split.step(a)
+        fused.step(a, auto_reset=True)
+        hf, hs = fused.host_state(), split.host_state()
+        for k in hf:
+            assert (hf[k].view(np.uint8) == hs[k].view(np.uint8)).all(), (k, t)
+        assert (fused.obs == split.obs).all(), t
+    assert n_resets > N          # every env went through several episodes
+    # rollout() is the same loop
+    acts = torch.randint(0, 4, (5, N), dtype=torch.int32, device="cuda")
+    fused.rollout(acts, auto_reset=True)
+    for t in range(5):
+        split.reset(mask=split.done)
+        split.step(acts[t])
+    assert (fused.obs == split.obs).all() and (fused.ball_xy == split.ball_xy).all()
+
+
+# ----------------------------------------------------------------------------------------
 # 5. reference-layout render vs oracle, incl. shapes whose C*S*S is not a multiple of 4
 # ----------------------------------------------------------------------------------------
 @pytest.mark.parametrize("G,E,cmask", [(12, 7, (1, 2, 4, 8)), (11, 7, (1, 2, 4, 8)), (18, 4, (8, 1, 4)),
