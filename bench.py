@@ -78,6 +78,12 @@ def main():
     ap.add_argument("--grid", type=int, default=None)
     ap.add_argument("--per-env-layouts", action="store_true", help="own random maze per env")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--auto-reset", action="store_true",
+                    help="lmaze_step_v0_autoreset: done envs are re-placed inside the step kernel (rollouts > 1 episode)")
+    ap.add_argument("--no-autotune", action="store_true",
+                    help="keep the library's default launch policy instead of LmazeVecEnv.autotune()")
+    ap.add_argument("--graph", action="store_true",
+                    help="capture the K timed launches into one hipGraph and time its replay (launch-bound sizes)")
     ap.add_argument("--action-rows", type=int, default=32, help="distinct pre-generated action rows (ring)")
     args = ap.parse_args()
 
@@ -125,6 +131,9 @@ def main():
         env = pkg.LmazeVecEnv(N, variant="v0", layout=layout, device=dev, seed=1, env_base=env_base)
         workload = "%d x %dx%d mazes per GPU, v0 rules, shared open-room layout, compact int32 obs" % (N, G, G)
 
+    tuned = None
+    if not args.no_autotune:
+        tuned = env.autotune(auto_reset=args.auto_reset)     # untimed: picks workgroups-per-CU for this shape/device
     gen = torch.Generator(device=dev).manual_seed(1 + rank)      # torch's device generator is Philox
     R = args.action_rows
     actions = torch.randint(0, 4, (R, N), dtype=torch.int32, device=dev, generator=gen)
@@ -132,7 +141,7 @@ def main():
 
     def run(k0, k):
         for t in range(k0, k0 + k):
-            env.step_raw(row_ptr[t % R])
+            env.step_raw(row_ptr[t % R], auto_reset=args.auto_reset)
 
     with torch.cuda.device(dev):
         run(0, args.warmup)
@@ -143,9 +152,21 @@ def main():
         # HIP events on the stream the kernels are launched on (torch's current stream)
         ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         t0 = time.perf_counter()
+        graph = None
+        if args.graph:
+            side = torch.cuda.Stream(device=dev)
+            side.wait_stream(torch.cuda.current_stream())
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.stream(side):
+                with torch.cuda.graph(graph, stream=side):
+                    run(args.warmup, args.steps)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
         ev0.record()
-        for t in range(args.steps):
-            env.step_raw(row_ptr[(args.warmup + t) % R])
+        if graph is not None:
+            graph.replay()
+        else:
+            run(args.warmup, args.steps)
         ev1.record()
         torch.cuda.synchronize()
         elapsed = time.perf_counter() - t0
@@ -158,7 +179,10 @@ def main():
     kern_ms = float(ev0.elapsed_time(ev1) / args.steps)   # ms per launch, launch gaps included
 
     # sanity: the run really stepped (every env advanced warmup+steps times)
-    assert int(env.step_count.min().item()) == args.warmup + args.steps
+    if not args.auto_reset:
+        assert int(env.step_count.min().item()) == args.warmup + args.steps
+    else:  # episodes restart: nobody is past the step limit, and everybody moved
+        assert 1 <= int(env.step_count.min().item()) and int(env.step_count.max().item()) <= env.step_limit
 
     if rank == 0:
         B = bytes_per_env_step(G, args.per_env_layouts)
@@ -182,7 +206,10 @@ def main():
             "vs_baseline": None, "dtype": "int32", "data": "synthetic",
             "config": {"workload": workload, "envs_per_gpu": N, "grid": G, "global_envs": world * N,
                        "parallelism": "independent env shards, no collective on the step path",
-                       "actions": "uniform{0..3} int32[%d,N] ring, torch Philox seed 1+rank" % R},
+                       "actions": "uniform{0..3} int32[%d,N] ring, torch Philox seed 1+rank" % R,
+                       "auto_reset": bool(args.auto_reset), "hip_graph": bool(args.graph),
+                       "launch_hint": int(env.params.launch_hint),
+                       "autotune_ms": {str(k): round(v, 5) for k, v in (tuned or {}).items()}},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "kernel": "lmaze::step_%s_kernel<%d, v0>" % ("perenv" if args.per_env_layouts else "shared", G),

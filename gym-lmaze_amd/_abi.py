@@ -27,7 +27,7 @@ class LmazeParams(C.Structure):
     """struct LmazeParams of include/lmaze.h (constants the reference hard-codes in __init__)."""
     _fields_ = [("variant", C.c_int32), ("grid", C.c_int32), ("layout_mode", C.c_int32),
                 ("step_limit", C.c_int32), ("reward_wall", C.c_float), ("reward_move", C.c_float),
-                ("reward_goal", C.c_float), ("reserved", C.c_int32)]
+                ("reward_goal", C.c_float), ("launch_hint", C.c_int32)]
 
 
 class LmazeError(RuntimeError):

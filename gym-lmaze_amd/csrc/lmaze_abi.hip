@@ -44,6 +44,7 @@ static StepArgs make_args(const LmazeParams* p, const uint8_t* layout, const int
     a.env_base = 0;
     a.goal_rw = nullptr;
     a.mask = nullptr;
+    a.launch_hint = p->launch_hint;
     return a;
 }
 

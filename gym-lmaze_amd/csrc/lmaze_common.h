@@ -34,6 +34,7 @@ struct StepArgs {
     int64_t env_base;
     int2* goal_rw;           // v3 + auto_reset: the goal array, writable
     const uint8_t* mask;     // observe only: re-render just the envs with mask != 0 (null = all)
+    int32_t launch_hint;     // LmazeParams.launch_hint (0 = library default policy)
 };
 
 // masked on-device reset (lmaze_aux.hip)

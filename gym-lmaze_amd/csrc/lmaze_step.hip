@@ -358,11 +358,34 @@ static size_t perenv_lds_bytes(int G, int epb) {
 // smaller buffers keep plain stores so the consumer of the observation finds them on-die.
 static const size_t kNonTemporalObsBytes = (size_t)192 << 20;
 
+// LDS bytes that make exactly `k` workgroups fit a CU's 160 KiB (midway between the k and
+// k+1 thresholds, clear of the allocation granule).
+static size_t lds_for_workgroups_per_cu(int k) {
+    const size_t cap = 160 * 1024;
+    return ((cap / k + cap / (k + 1)) / 2) & ~(size_t)255;
+}
+
+// Launch policy of the streaming (non-temporal) regime, measured on MI355X with
+// tools/kbench.hip (one process, interleaved rounds), workgroups per CU = 8 (no cap) / 4 / 3 / 2:
+//   1M x 11x11 (546 MB)   99-101 / 91-97 / 78-79 / 102 us     4M x 11x11   354 / 350 / 320 / 424 us
+//   2M x 8x8   (614 MB)   99 / 97 / 92 / 88 us                128K x 32x32   99 / 96 / 92 / 106 us
+//   1M x 12x12, 512K x 18x18: flat within 3 %
+// i.e. up to 6.9 TB/s instead of 5.5 when only 12 waves per CU stream their 32-KiB chunks (more
+// resident waves queue more non-temporal stores than the memory side drains efficiently; with
+// plain stores the cap hurts).  The optimum is narrow and shifts with shape and device, so the
+// caller can override it: LmazeParams.launch_hint bits 0-3 = workgroups per CU (0 = this
+// default), which LmazeVecEnv.autotune() picks by timing real steps.
 template <int GT, int VARIANT, bool DO_STEP, int EPB>
 static hipError_t launch_shared(const StepArgs& a, hipStream_t s) {
     const int64_t blocks = (a.n + EPB - 1) / EPB;
-    const size_t lds = shared_lds_bytes(a.grid, GT != 0, EPB);
+    size_t lds = shared_lds_bytes(a.grid, GT != 0, EPB);
     const bool nt = a.obs != nullptr && (size_t)a.n * a.grid * a.grid * 4 > kNonTemporalObsBytes;
+    int per_cu = a.launch_hint & 15;
+    if (per_cu == 0 && nt) per_cu = 3;
+    if (per_cu >= 1 && per_cu < 8) {
+        const size_t want = lds_for_workgroups_per_cu(per_cu);
+        if (want > lds) lds = want;
+    }
     if (nt)
         hipLaunchKernelGGL((step_shared_kernel<GT, VARIANT, DO_STEP, EPB, true>), dim3((unsigned)blocks),
                            dim3(LMAZE_BLOCK), lds, s, a);

@@ -73,7 +73,9 @@ typedef struct LmazeParams {
     float reward_wall;   /* negativeNominal  -1.0   (v0:21)                                  */
     float reward_move;   /* positiveNominal  -0.01  (v0:22)                                  */
     float reward_goal;   /* positiveFull    100.0   (v0:23)                                  */
-    int32_t reserved;    /* must be 0                                                        */
+    int32_t launch_hint; /* 0 = library default launch policy; else bits 0-3 = workgroups per
+                            CU, 1..8 (performance only, never results; lmaze_step.hip
+                            launch_shared; other bits must be 0)                             */
 } LmazeParams;
 
 int lmaze_abi_version(void);

@@ -20,7 +20,7 @@ OBS_BALL, OBS_WALL, OBS_GOAL, OBS_FREE = 1, 2, 4, 8
 class Params(C.Structure):
     _fields_ = [("variant", C.c_int32), ("grid", C.c_int32), ("layout_mode", C.c_int32),
                 ("step_limit", C.c_int32), ("reward_wall", C.c_float), ("reward_move", C.c_float),
-                ("reward_goal", C.c_float), ("reserved", C.c_int32)]
+                ("reward_goal", C.c_float), ("launch_hint", C.c_int32)]
 
 
 def build(force=False):

@@ -59,7 +59,7 @@ def test_abi_version_and_errors(abi):
 def test_params_struct_layout(abi):
     assert C.sizeof(abi.LmazeParams) == 32
     assert [f[0] for f in abi.LmazeParams._fields_] == ["variant", "grid", "layout_mode", "step_limit",
-                                                        "reward_wall", "reward_move", "reward_goal", "reserved"]
+                                                        "reward_wall", "reward_move", "reward_goal", "launch_hint"]
 
 
 def test_no_device_is_loud(abi):

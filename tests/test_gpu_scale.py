@@ -140,3 +140,25 @@ def test_graph_capture_replays_steps():
     torch.cuda.synchronize()
     assert (env_a.obs == env_b.obs).all() and (env_a.ball_xy == env_b.ball_xy).all()
     assert (env_a.step_count == env_b.step_count).all()
+
+
+def test_autotune_keeps_results_and_state():
+    """autotune() times real steps under each launch policy, restores the state, and any hint
+    gives bit-identical results (the hint only changes occupancy)."""
+    N, G = 1 << 19, 11                     # 254 MB of obs: the non-temporal regime (> 192 MiB)
+    lay = L.to_codes(L.open_room(G, (5, 5)))
+    env = PKG.LmazeVecEnv(N, variant="v0", layout=lay, seed=6)
+    ref = PKG.LmazeVecEnv(N, variant="v0", layout=lay, seed=6)
+    before = env._state.clone()
+    t = env.autotune()
+    assert set(t) == {8, 4, 3, 2} and env.params.launch_hint in t
+    assert (env._state == before).all()
+    acts = torch.randint(0, 4, (4, N), dtype=torch.int32, device="cuda")
+    for hint in (0, 2, 3, 5, 8):
+        env.params.launch_hint = hint
+        env._state.copy_(before)
+        ref._state.copy_(before)
+        for k in range(4):
+            env.step(acts[k])
+            ref.step(acts[k])
+        assert (env.obs == ref.obs).all() and (env._state == ref._state).all(), hint
