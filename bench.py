@@ -56,7 +56,7 @@ def cpu_baseline(G, layout_codes, budget_s=12.0):
     t0 = time.perf_counter()
     O.step_v0(p, lay, acts[1], ball, sc, rew, done, gc, obs)
     one = max(time.perf_counter() - t0, 1e-6)
-    steps = int(max(4, min(2000, budget_s / one)))
+    steps = int(max(4, min(20000, budget_s / one)))
     t0 = time.perf_counter()
     for t in range(steps):
         O.step_v0(p, lay, acts[t & 7], ball, sc, rew, done, gc, obs)
@@ -82,6 +82,9 @@ def main():
                     help="lmaze_step_v0_autoreset: done envs are re-placed inside the step kernel (rollouts > 1 episode)")
     ap.add_argument("--no-autotune", action="store_true",
                     help="keep the library's default launch policy instead of LmazeVecEnv.autotune()")
+    ap.add_argument("--launch-hint", type=int, default=None,
+                    help="fixed LmazeParams.launch_hint (workgroups per CU), skipping the autotune; used for the "
+                         "rocprofv3 passes so that every profiled launch runs the policy the bench line was measured with")
     ap.add_argument("--graph", action="store_true",
                     help="capture the K timed launches into one hipGraph and time its replay (launch-bound sizes)")
     ap.add_argument("--action-rows", type=int, default=32, help="distinct pre-generated action rows (ring)")
@@ -132,7 +135,9 @@ def main():
         workload = "%d x %dx%d mazes per GPU, v0 rules, shared open-room layout, compact int32 obs" % (N, G, G)
 
     tuned = None
-    if not args.no_autotune:
+    if args.launch_hint is not None:
+        env.params.launch_hint = args.launch_hint
+    elif not args.no_autotune:
         tuned = env.autotune(auto_reset=args.auto_reset)     # untimed: picks workgroups-per-CU for this shape/device
     gen = torch.Generator(device=dev).manual_seed(1 + rank)      # torch's device generator is Philox
     R = args.action_rows
