@@ -176,6 +176,90 @@ int lmaze_render_expanded(const int32_t* obs, int32_t grid, int32_t expansion,
                           const int32_t* channel_mask_host, int32_t channels, float* out,
                           int64_t n, void* stream);
 
+/* ====================================================================================== */
+/* Foveal variants: the agent sees a 5x5 window (a8 crop, a9 frame history of SURVEY 8a).  */
+/*   v1 = gym_lmaze/envs/lmaze_env_v1.py   v2 = lmaze_env_v2.py   v4 = lmaze_env_v4.py       */
+/* The observation is float[N,C,5,5]: exactly the reference's `retState` before its xE loop   */
+/* (v1 C=4: v1:242-256; v2 C=5: v2:185-193; v4 C=7: v4:231-239); lmaze_expand_planes makes    */
+/* the (C,35,35) reference layout from it.                                                    */
+/* ====================================================================================== */
+enum {
+    LMAZE_VARIANT_V1 = 1, /* LmazeEnv_v1 (v1:114-200): 4-neighbour move, two reward streams, foveal goal */
+    LMAZE_VARIANT_V2 = 2, /* LmazeEnv_v2 (v2:127-225): 25-way teleport inside the fovea, 5 layouts       */
+    LMAZE_VARIANT_V4 = 4  /* LmazeEnv_v4 (v4:167-272): v2 + float visit-map plane                        */
+};
+
+#define LMAZE_FOVEA 5
+#define LMAZE_MAX_LAYOUTS 16
+
+typedef struct LmazeFovealParams {
+    int32_t variant;            /* LMAZE_VARIANT_V1 / V2 / V4                                          */
+    int32_t grid;               /* G (v1: 14, v1:22; v2/v4: 18)                                        */
+    int32_t n_layouts;          /* rows of the layout table uint8[L,G,G] (v1: 1; v2/v4: 5, v2:309-405) */
+    int32_t step_limit;         /* v1: done at stepCount == 200 (v1:295); v2/v4: > 50 (v2:222)         */
+    int32_t foveal_step_limit;  /* v1: fovealStepCount == 10 (v1:309); unused by v2/v4                 */
+    float reward_wall;          /* negativeNominal -1.0                                                 */
+    float reward_move;          /* positiveNominal v1 +0.01 (v1:28); v2/v4 -0.01 (v2:47)               */
+    float reward_goal;          /* positiveFull    v1 1.0 (v1:29);   v2/v4 100.0                       */
+} LmazeFovealParams;
+
+/* Device pointers, one element per env; entries a variant does not use may be NULL. */
+typedef struct LmazeFovealBuffers {
+    int32_t* ball_xy;           /* [N,2] ball_x0, ball_y0 (window centre)                               */
+    int32_t* goal_xy;           /* [N,2] goal_x, goal_y             v2, v4 (v1 reads 'X' off the layout) */
+    int32_t* fgoal_xy;          /* [N,2] f_goal_x, f_goal_y         v1 (v1:104-110)                     */
+    int32_t* layout_id;         /* [N]   row of the layout table    v2, v4 (v2:306)                     */
+    int32_t* step_count;        /* [N]   stepCount                                                      */
+    int32_t* foveal_step_count; /* [N]   fovealStepCount            v1 (not reset by reset(), v1:94)    */
+    float* reward;              /* [N]   originalReward                                                 */
+    float* foveal_reward;       /* [N]   fovealReward               v1                                  */
+    uint8_t* done;              /* [N]                                                                  */
+    uint8_t* foveal_done;       /* [N]   isFovealEpisodeFinished()  v1 (v1:308-324)                     */
+    float* visit;               /* [N,G,G] visit map state[2]       v4 (v4:116-119,211-214)             */
+    float* obs;                 /* [N,C,5,5], 16-byte aligned                                           */
+} LmazeFovealBuffers;
+
+/*
+ * One step() of N foveal envs (v1:114-200 | v2:127-225 | v4:167-272).
+ *   layouts  uint8[L,G,G] device; action int32[N] (v1: 0..3 else no move; v2/v4: 0..24 =
+ *   5*row+col of the target cell inside the window; the reference raises IndexError outside
+ *   that range before it changes anything, here such an id leaves the env -- state and obs --
+ *   untouched).
+ * Layouts need the reference's 2-cell (v1) / 4-cell (v2, v4) 'W' padding so the window never
+ * leaves the array (v1:40-53, v2:309-326).
+ */
+int lmaze_foveal_step(const LmazeFovealParams* params, const uint8_t* layouts, const int32_t* action,
+                      const LmazeFovealBuffers* bufs, int64_t n, void* stream);
+
+/*
+ * reset() of the envs with mask[i] != 0 (NULL = all): step_count = 0, rewards = -0.0, done
+ * flags cleared, v4 visit map re-initialised ((0 + window)/2, v4:116-119), and the reset
+ * observation written (v1: global view v1:204-238; v2/v4: [window, zero action plane, window],
+ * v2:109-110).  place != 0 also draws the placement on the device with Philox4x32-10 keyed by
+ * (seed, env_base + i, epoch): v1 ball = the 'S' cell (v1:82-84); v2 goal, ball on the CURRENT
+ * layout and only then a new layout_id (the reset-order quirk of v2:90-92); v4 layout_id first
+ * (v4:97-104).  place == 0 keeps the caller's ball/goal/layout_id (e.g. the reference's own
+ * draws).  Unmasked envs are untouched, their obs included.
+ */
+int lmaze_foveal_reset(const LmazeFovealParams* params, const uint8_t* layouts, const uint8_t* mask,
+                       int32_t place, uint64_t seed, uint64_t epoch, int64_t env_base,
+                       const LmazeFovealBuffers* bufs, int64_t n, void* stream);
+
+/*
+ * v1 setFovealGoal(i, j) (v1:104-110) for the envs with mask[i] != 0 (NULL = all):
+ * f_goal = ball + (i, j) - 2, fovealStepCount = 0, obs = local view (v1:242-279).
+ *   ij int32[N,2]
+ */
+int lmaze_v1_set_foveal_goal(const LmazeFovealParams* params, const uint8_t* layouts, const int32_t* ij,
+                             const uint8_t* mask, const LmazeFovealBuffers* bufs, int64_t n, void* stream);
+
+/*
+ * The xE nearest-neighbour loop on float planes (v1:258-277, v2:197-203, v4:243-249):
+ * out[i, c, x*E+xx, y*E+yy] = planes[i, c, x, y].   planes float[N,C,g,g]; out 16-byte aligned.
+ */
+int lmaze_expand_planes(const float* planes, int32_t channels, int32_t g, int32_t expansion, float* out,
+                        int64_t n, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

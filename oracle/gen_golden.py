@@ -246,7 +246,191 @@ def gen_v3():
     save("v3_g11_open_seed3", rollout_v3(mixed_actions(34, 300), seed=3, grid=layout_open_room(11, (5, 5))))
 
 
-GENERATORS = {"v0": gen_v0, "v3": gen_v3}
+# ----------------------------------------------------------------------------------------
+# foveal variants (5x5 window observations): v1, v2, v4, v5/v6
+#   planes   float32[T,C,5,5]   obs[:, ::E, ::E] (v4-v6 carry a float visit-map plane), after the
+#                               same exact-replication check
+# ----------------------------------------------------------------------------------------
+def unexpand(obs, E):
+    obs = np.asarray(obs)
+    comp = np.ascontiguousarray(obs[:, ::E, ::E]).astype(np.float32)
+    rep = np.repeat(np.repeat(comp, E, axis=1), E, axis=2)
+    assert obs.dtype == np.float32 and rep.shape == obs.shape and (rep == obs).all(), "not an exact ExE replication"
+    return comp
+
+
+_FIVE = None
+
+
+def five_layouts():
+    """The five 18x18 layouts setGrid() chooses from (lmaze_env_v2.py:309-405), read off a live object."""
+    global _FIVE
+    if _FIVE is None:
+        import numpy.random as npr
+        env = ref_loader.make("v2")
+        orig = npr.randint
+        tabs = []
+        try:
+            for k in range(1, 6):
+                npr.randint = lambda a, b, k=k: k
+                env.setGrid()
+                tabs.append(to_codes(env.grid))
+        finally:
+            npr.randint = orig
+        _FIVE = np.stack(tabs)
+    return _FIVE
+
+
+def layout_id_of(grid):
+    codes = to_codes(grid)
+    for k, t in enumerate(five_layouts()):
+        if t.shape == codes.shape and (t == codes).all():
+            return k
+    raise AssertionError("grid is not one of the five shipped layouts")
+
+
+def foveal_actions(seed, T):
+    return np.random.RandomState(seed).randint(0, 25, T).astype(np.int32)
+
+
+def rollout_v24(variant, actions, seed, reset_on_done=True):
+    """v2 (lmaze_env_v2.py) and v4 (lmaze_env_v4.py): 25-way teleport-in-fovea action."""
+    five_layouts()
+    import contextlib
+    import io
+    random.seed(seed)
+    np.random.seed(seed)
+    env = ref_loader.make(variant)          # the constructor already ran one reset()
+    E, C = env.expansionRatio, env.stateChannel
+    T = len(actions)
+    rec = dict(E=np.int32(E), seed=np.int64(seed), layouts=five_layouts(),
+               actions=np.asarray(actions, dtype=np.int32),
+               reset_before=np.zeros(T, np.uint8), ball_before=np.zeros((T, 2), np.int32),
+               goal_before=np.zeros((T, 2), np.int32), layout_id=np.zeros(T, np.int32),
+               reward=np.zeros(T, np.float64), done=np.zeros(T, np.uint8),
+               ball=np.zeros((T, 2), np.int32), step_count=np.zeros(T, np.int32),
+               planes=np.zeros((T, C, 5, 5), np.float32), obs_hash=np.zeros(T, np.uint64))
+    reset_planes, reset_hash = [], []
+    need_reset = True
+    first = None
+    for t in range(T):
+        if need_reset:
+            o = env.reset()
+            reset_planes.append(unexpand(o, E))
+            reset_hash.append(obs_hash(o))
+            rec["reset_before"][t] = 1
+            need_reset = False
+        rec["ball_before"][t] = (env.ball_x0, env.ball_y0)
+        rec["goal_before"][t] = (env.goal_x, env.goal_y)
+        rec["layout_id"][t] = layout_id_of(env.grid)
+        with contextlib.redirect_stdout(io.StringIO()):   # v4 prints state[2] on done (lmaze_env_v4.py:269)
+            o, r, d, info = env.step(actions[t])
+        first = o if first is None else first
+        assert o is first and info == int(actions[t]) and o.shape == (C, 5 * E, 5 * E)
+        rec["reward"][t] = r
+        rec["done"][t] = d
+        rec["ball"][t] = (env.ball_x0, env.ball_y0)
+        rec["step_count"][t] = env.stepCount
+        rec["planes"][t] = unexpand(o, E)
+        rec["obs_hash"][t] = obs_hash(o)
+        if d and reset_on_done:
+            need_reset = True
+    rec["reset_planes"] = np.stack(reset_planes)
+    rec["reset_hash"] = np.array(reset_hash, np.uint64)
+    return rec
+
+
+def rollout_v1(actions, fgoals, seed, reset_on_done=True):
+    """v1 (lmaze_env_v1.py): 14x14, 5x5 window, foveal goal set by setFovealGoal(i, j) whenever the
+    foveal episode finished (the two-level loop the class is written for)."""
+    rs = np.random.RandomState(seed)
+    env = ref_loader.make("v1")
+    E = env.expansionRatio
+    T = len(actions)
+    rec = dict(layout=to_codes(env.grid), E=np.int32(E), seed=np.int64(seed),
+               actions=np.asarray(actions, dtype=np.int32),
+               reset_before=np.zeros(T, np.uint8), setgoal_before=np.zeros(T, np.uint8),
+               setgoal_ij=np.zeros((T, 2), np.int32),
+               ball_before=np.zeros((T, 2), np.int32), fgoal_before=np.zeros((T, 2), np.int32),
+               fstep_before=np.zeros(T, np.int32),
+               reward=np.zeros(T, np.float64), foveal_reward=np.zeros(T, np.float64),
+               done=np.zeros(T, np.uint8), foveal_done=np.zeros(T, np.uint8),
+               ball=np.zeros((T, 2), np.int32), step_count=np.zeros(T, np.int32),
+               foveal_step_count=np.zeros(T, np.int32),
+               planes=np.zeros((T, 4, 5, 5), np.float32), obs_hash=np.zeros(T, np.uint64),
+               setgoal_planes=np.zeros((T, 4, 5, 5), np.float32))
+    reset_planes, reset_hash = [], []
+    need_reset, need_goal = True, True
+    k = 0
+    for t in range(T):
+        if need_reset:
+            o = env.reset()
+            reset_planes.append(unexpand(o, E))
+            reset_hash.append(obs_hash(o))
+            rec["reset_before"][t] = 1
+            need_reset, need_goal = False, True
+        if need_goal:
+            i, j = fgoals[k % len(fgoals)]
+            k += 1
+            o = env.setFovealGoal(int(i), int(j))
+            rec["setgoal_before"][t] = 1
+            rec["setgoal_ij"][t] = (i, j)
+            rec["setgoal_planes"][t] = unexpand(o, E)
+            need_goal = False
+        rec["ball_before"][t] = (env.ball_x0, env.ball_y0)
+        rec["fgoal_before"][t] = (env.f_goal_x, env.f_goal_y)
+        rec["fstep_before"][t] = env.fovealStepCount
+        a = int(actions[t])
+        o, r, fr, fd, d, info = env.step(a)
+        assert info == a and o.shape == (4, 5 * E, 5 * E)
+        rec["reward"][t] = r
+        rec["foveal_reward"][t] = fr
+        rec["done"][t] = d
+        rec["foveal_done"][t] = fd
+        rec["ball"][t] = (env.ball_x0, env.ball_y0)
+        rec["step_count"][t] = env.stepCount
+        rec["foveal_step_count"][t] = env.fovealStepCount
+        rec["planes"][t] = unexpand(o, E)
+        rec["obs_hash"][t] = obs_hash(o)
+        if d and reset_on_done:
+            need_reset = True
+        elif fd:
+            need_goal = True
+    rec["goal"] = np.array([env.goal_x, env.goal_y], np.int32)
+    rec["reset_planes"] = np.stack(reset_planes)
+    rec["reset_hash"] = np.array(reset_hash, np.uint64)
+    return rec
+
+
+def gen_v2():
+    save("v2_seed0", rollout_v24("v2", foveal_actions(41, 400), seed=0))
+    save("v2_seed1", rollout_v24("v2", foveal_actions(42, 300), seed=1))
+    save("v2_noreset_seed2", rollout_v24("v2", foveal_actions(43, 150), seed=2, reset_on_done=False))
+
+
+def gen_v4():
+    save("v4_seed0", rollout_v24("v4", foveal_actions(51, 400), seed=0))
+    save("v4_seed1", rollout_v24("v4", foveal_actions(52, 300), seed=1))
+    save("v4_noreset_seed2", rollout_v24("v4", foveal_actions(53, 150), seed=2, reset_on_done=False))
+
+
+def gen_v1():
+    rs = np.random.RandomState(61)
+    fg = rs.randint(0, 5, (64, 2))
+    save("v1_seed0", rollout_v1(mixed_actions(62, 600, lo=-1, hi=5), fg, seed=0))
+    # foveal goals kept inside the reachable cross so local goals get hit
+    fg2 = np.array([(2, 3), (3, 2), (2, 1), (1, 2), (2, 2), (2, 4), (4, 2)])
+    save("v1_seed1", rollout_v1(np.random.RandomState(63).randint(0, 4, 500).astype(np.int32), fg2, seed=1))
+    save("v1_noreset_seed2", rollout_v1(mixed_actions(64, 450), fg, seed=2, reset_on_done=False))
+    # scripted: walk S(2,2) -> X(6,6) twice (global reward 1.0 / done), some wall bumps in between, with
+    # foveal goals chosen one step ahead so the local goal is hit too
+    path = [1, 1, 1, 1, 3, 3, 1, 1, 1, 3, 3, 0, 0, 0]
+    acts = np.array(path + [0, 2, 7] + path + [0], np.int32)
+    fg3 = np.array([(3, 2), (2, 3), (1, 2), (3, 2), (2, 3)])
+    save("v1_scripted_goal", rollout_v1(acts, fg3, seed=3))
+
+
+GENERATORS = {"v0": gen_v0, "v3": gen_v3, "v1": gen_v1, "v2": gen_v2, "v4": gen_v4}
 
 if __name__ == "__main__":
     which = sys.argv[1:] or sorted(GENERATORS)

@@ -27,7 +27,8 @@ def build(force=False):
     src = os.path.join(HERE, "lmaze_oracle.c")
     hdr = os.path.join(os.path.dirname(HERE), "include", "lmaze.h")
     if (force or not os.path.exists(LIB_PATH)
-            or os.path.getmtime(LIB_PATH) < max(os.path.getmtime(src), os.path.getmtime(hdr))):
+            or os.path.getmtime(LIB_PATH) < max(os.path.getmtime(src), os.path.getmtime(hdr),
+                                                os.path.getmtime(os.path.join(HERE, "lmaze_oracle_foveal.c")))):
         subprocess.check_call(["make", "-C", HERE, "-s", "-B", "liblmaze_oracle.so"])
     return LIB_PATH
 
@@ -123,3 +124,88 @@ def philox4x32_10(ctr, key):
     o = (C.c_uint32 * 4)()
     lib().lmaze_oracle_philox4x32_10(c, k, o)
     return [int(x) for x in o]
+
+
+# ---------------------------------------------------------------------------------------
+# foveal variants (lmaze_oracle_foveal.c)
+# ---------------------------------------------------------------------------------------
+VARIANT_V1, VARIANT_V2, VARIANT_V4 = 1, 2, 4
+FOVEAL_CHANNELS = {VARIANT_V1: 4, VARIANT_V2: 5, VARIANT_V4: 7}
+
+
+class FovealParams(C.Structure):
+    _fields_ = [("variant", C.c_int32), ("grid", C.c_int32), ("n_layouts", C.c_int32), ("step_limit", C.c_int32),
+                ("foveal_step_limit", C.c_int32), ("reward_wall", C.c_float), ("reward_move", C.c_float),
+                ("reward_goal", C.c_float)]
+
+
+class FovealBuffers(C.Structure):
+    _fields_ = [(n, C.c_void_p) for n in ("ball_xy", "goal_xy", "fgoal_xy", "layout_id", "step_count",
+                                          "foveal_step_count", "reward", "foveal_reward", "done", "foveal_done",
+                                          "visit", "obs")]
+
+
+def foveal_params(variant, grid, n_layouts):
+    if variant == VARIANT_V1:      # lmaze_env_v1.py:22-29
+        return FovealParams(variant, grid, n_layouts, 200, 10, -1.0, 0.01, 1.0)
+    return FovealParams(variant, grid, n_layouts, 50, 0, -1.0, -0.01, 100.0)   # lmaze_env_v2.py:43-49
+
+
+class FovealState(object):
+    """numpy arrays for one batch + the struct of pointers the C functions take."""
+
+    def __init__(self, variant, n, grid):
+        Cn = FOVEAL_CHANNELS[variant]
+        self.ball_xy = np.zeros((n, 2), np.int32)
+        self.goal_xy = np.zeros((n, 2), np.int32)
+        self.fgoal_xy = np.zeros((n, 2), np.int32)
+        self.layout_id = np.zeros(n, np.int32)
+        self.step_count = np.zeros(n, np.int32)
+        self.foveal_step_count = np.zeros(n, np.int32)
+        self.reward = np.zeros(n, np.float32)
+        self.foveal_reward = np.zeros(n, np.float32)
+        self.done = np.zeros(n, np.uint8)
+        self.foveal_done = np.zeros(n, np.uint8)
+        self.visit = np.zeros((n, grid, grid), np.float32)
+        self.obs = np.zeros((n, Cn, 5, 5), np.float32)
+        self.n = n
+
+    def struct(self):
+        return FovealBuffers(*[getattr(self, f[0]).ctypes.data for f in FovealBuffers._fields_])
+
+
+def foveal_step(p, layouts, action, st):
+    b = st.struct()
+    rc = lib().lmaze_oracle_foveal_step(C.byref(p), _p(layouts, C.c_uint8), _p(action, C.c_int32), C.byref(b),
+                                        C.c_int64(st.n))
+    if rc:
+        raise RuntimeError("lmaze_oracle_foveal_step -> %d" % rc)
+
+
+def foveal_reset(p, layouts, mask, place, seed, epoch, st, env_base=0):
+    b = st.struct()
+    rc = lib().lmaze_oracle_foveal_reset(C.byref(p), _p(layouts, C.c_uint8), _p(mask, C.c_uint8), C.c_int32(place),
+                                         C.c_uint64(seed), C.c_uint64(epoch), C.c_int64(env_base), C.byref(b),
+                                         C.c_int64(st.n))
+    if rc:
+        raise RuntimeError("lmaze_oracle_foveal_reset -> %d" % rc)
+
+
+def v1_set_foveal_goal(p, layouts, ij, mask, st):
+    b = st.struct()
+    ij = np.ascontiguousarray(ij, dtype=np.int32)
+    rc = lib().lmaze_oracle_v1_set_foveal_goal(C.byref(p), _p(layouts, C.c_uint8), _p(ij, C.c_int32),
+                                               _p(mask, C.c_uint8), C.byref(b), C.c_int64(st.n))
+    if rc:
+        raise RuntimeError("lmaze_oracle_v1_set_foveal_goal -> %d" % rc)
+
+
+def expand_planes(planes, expansion):
+    planes = np.ascontiguousarray(planes, dtype=np.float32)
+    n, ch, g, _ = planes.shape
+    out = np.empty((n, ch, g * expansion, g * expansion), np.float32)
+    rc = lib().lmaze_oracle_expand_planes(_p(planes, C.c_float), C.c_int32(ch), C.c_int32(g), C.c_int32(expansion),
+                                          _p(out, C.c_float), C.c_int64(n))
+    if rc:
+        raise RuntimeError("lmaze_oracle_expand_planes -> %d" % rc)
+    return out

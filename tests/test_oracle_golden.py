@@ -74,3 +74,71 @@ def test_philox_known_answers():
     assert O.philox4x32_10([0xffffffff] * 4, [0xffffffff] * 2) == [0x408f276d, 0x41c83b0e, 0xa20bc7c6, 0x6d5451fd]
     assert O.philox4x32_10([0x243f6a88, 0x85a308d3, 0x13198a2e, 0x03707344],
                            [0xa4093822, 0x299f31d0]) == [0xd16cfe09, 0x94fdcceb, 0x5001e420, 0x24126ea1]
+
+
+# ---------------------------------------------------------------------------------------
+# foveal variants: v1 (setFovealGoal + two reward streams), v2 (teleport), v4 (visit map)
+# ---------------------------------------------------------------------------------------
+def _replay_v24(g, variant):
+    layouts = np.ascontiguousarray(g["layouts"])
+    G, E = layouts.shape[-1], int(g["E"])
+    p = O.foveal_params(variant, G, layouts.shape[0])
+    st = O.FovealState(variant, 1, G)
+    n_reset = 0
+    for t in range(len(g["actions"])):
+        if g["reset_before"][t]:
+            st.ball_xy[0] = g["ball_before"][t]
+            st.goal_xy[0] = g["goal_before"][t]
+            st.layout_id[0] = g["layout_id"][t]
+            O.foveal_reset(p, layouts, None, 0, 0, 0, st)           # place=0: the reference's own draws
+            assert (st.obs[0].view(np.uint32) == g["reset_planes"][n_reset].view(np.uint32)).all()
+            assert obs_hash(O.expand_planes(st.obs, E)[0]) == g["reset_hash"][n_reset]
+            n_reset += 1
+        assert tuple(st.ball_xy[0]) == tuple(g["ball_before"][t]) and st.layout_id[0] == g["layout_id"][t]
+        O.foveal_step(p, layouts, g["actions"][t:t + 1].copy(), st)
+        assert f32_bits(st.reward)[0] == ref_reward_bits(g["reward"][t]), t
+        assert st.done[0] == g["done"][t] and st.step_count[0] == g["step_count"][t], t
+        assert tuple(st.ball_xy[0]) == tuple(g["ball"][t]), t
+        assert (st.obs[0].view(np.uint32) == g["planes"][t].view(np.uint32)).all(), t
+        assert obs_hash(O.expand_planes(st.obs, E)[0]) == g["obs_hash"][t], t
+    assert n_reset == len(g["reset_hash"])
+
+
+@pytest.mark.parametrize("name", golden_files("v2_"))
+def test_oracle_v2_matches_reference(name):
+    _replay_v24(load_golden(name), O.VARIANT_V2)
+
+
+@pytest.mark.parametrize("name", golden_files("v4_"))
+def test_oracle_v4_matches_reference(name):
+    _replay_v24(load_golden(name), O.VARIANT_V4)
+
+
+@pytest.mark.parametrize("name", golden_files("v1_"))
+def test_oracle_v1_matches_reference(name):
+    g = load_golden(name)
+    layout = np.ascontiguousarray(g["layout"])[None]
+    G, E = layout.shape[-1], int(g["E"])
+    p = O.foveal_params(O.VARIANT_V1, G, 1)
+    st = O.FovealState(O.VARIANT_V1, 1, G)
+    n_reset = 0
+    for t in range(len(g["actions"])):
+        if g["reset_before"][t]:
+            O.foveal_reset(p, layout, None, 1, 0, 0, st)            # v1 placement is deterministic ('S')
+            assert (st.obs[0].view(np.uint32) == g["reset_planes"][n_reset].view(np.uint32)).all()
+            assert obs_hash(O.expand_planes(st.obs, E)[0]) == g["reset_hash"][n_reset]
+            n_reset += 1
+        if g["setgoal_before"][t]:
+            O.v1_set_foveal_goal(p, layout, g["setgoal_ij"][t:t + 1], None, st)
+            assert (st.obs[0].view(np.uint32) == g["setgoal_planes"][t].view(np.uint32)).all(), t
+        assert tuple(st.ball_xy[0]) == tuple(g["ball_before"][t]) and tuple(st.fgoal_xy[0]) == tuple(g["fgoal_before"][t])
+        assert st.foveal_step_count[0] == g["fstep_before"][t]
+        O.foveal_step(p, layout, g["actions"][t:t + 1].copy(), st)
+        assert f32_bits(st.reward)[0] == ref_reward_bits(g["reward"][t]), t
+        assert f32_bits(st.foveal_reward)[0] == ref_reward_bits(g["foveal_reward"][t]), t
+        assert st.done[0] == g["done"][t] and st.foveal_done[0] == g["foveal_done"][t], t
+        assert st.step_count[0] == g["step_count"][t] and st.foveal_step_count[0] == g["foveal_step_count"][t], t
+        assert tuple(st.ball_xy[0]) == tuple(g["ball"][t]), t
+        assert (st.obs[0].view(np.uint32) == g["planes"][t].view(np.uint32)).all(), t
+        assert obs_hash(O.expand_planes(st.obs, E)[0]) == g["obs_hash"][t], t
+    assert n_reset == len(g["reset_hash"])
