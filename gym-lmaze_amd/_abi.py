@@ -12,6 +12,8 @@ LIB_PATH = os.path.join(HERE, "liblmaze_hip.so")
 
 ABI_VERSION = 1
 VARIANT_V0, VARIANT_V3 = 0, 3
+VARIANT_V1, VARIANT_V2, VARIANT_V4 = 1, 2, 4
+FOVEA = 5
 LAYOUT_SHARED, LAYOUT_PER_ENV = 0, 1
 OBS_BALL, OBS_WALL, OBS_GOAL, OBS_FREE = 1, 2, 4, 8
 MAX_GRID, MAX_CHANNELS = 64, 8
@@ -20,7 +22,8 @@ MAX_GRID, MAX_CHANNELS = 64, 8
 # checks this list and the loaded library against it)
 SYMBOLS = ("lmaze_abi_version", "lmaze_strerror", "lmaze_device_info", "lmaze_step_v0", "lmaze_step_v3",
            "lmaze_step_v0_autoreset", "lmaze_step_v3_autoreset", "lmaze_observe", "lmaze_reset",
-           "lmaze_render_expanded")
+           "lmaze_render_expanded", "lmaze_foveal_step", "lmaze_foveal_reset", "lmaze_v1_set_foveal_goal",
+           "lmaze_expand_planes")
 
 
 class LmazeParams(C.Structure):
@@ -28,6 +31,22 @@ class LmazeParams(C.Structure):
     _fields_ = [("variant", C.c_int32), ("grid", C.c_int32), ("layout_mode", C.c_int32),
                 ("step_limit", C.c_int32), ("reward_wall", C.c_float), ("reward_move", C.c_float),
                 ("reward_goal", C.c_float), ("launch_hint", C.c_int32)]
+
+
+class LmazeFovealParams(C.Structure):
+    """struct LmazeFovealParams of include/lmaze.h."""
+    _fields_ = [("variant", C.c_int32), ("grid", C.c_int32), ("n_layouts", C.c_int32), ("step_limit", C.c_int32),
+                ("foveal_step_limit", C.c_int32), ("reward_wall", C.c_float), ("reward_move", C.c_float),
+                ("reward_goal", C.c_float)]
+
+
+FOVEAL_BUFFER_FIELDS = ("ball_xy", "goal_xy", "fgoal_xy", "layout_id", "step_count", "foveal_step_count",
+                        "reward", "foveal_reward", "done", "foveal_done", "visit", "obs")
+
+
+class LmazeFovealBuffers(C.Structure):
+    """struct LmazeFovealBuffers of include/lmaze.h: device pointers, one element per env."""
+    _fields_ = [(n, C.c_void_p) for n in FOVEAL_BUFFER_FIELDS]
 
 
 class LmazeError(RuntimeError):
@@ -64,6 +83,15 @@ def _load():
     lib.lmaze_reset.argtypes = [P, vp, vp, u64, u64, i64, vp, vp, vp, vp, vp, vp, i64, vp]
     lib.lmaze_render_expanded.restype = C.c_int
     lib.lmaze_render_expanded.argtypes = [vp, i32, i32, C.POINTER(i32), i32, vp, i64, vp]
+    FP, FB = C.POINTER(LmazeFovealParams), C.POINTER(LmazeFovealBuffers)
+    lib.lmaze_foveal_step.restype = C.c_int
+    lib.lmaze_foveal_step.argtypes = [FP, vp, vp, FB, i64, vp]
+    lib.lmaze_foveal_reset.restype = C.c_int
+    lib.lmaze_foveal_reset.argtypes = [FP, vp, vp, i32, u64, u64, i64, FB, i64, vp]
+    lib.lmaze_v1_set_foveal_goal.restype = C.c_int
+    lib.lmaze_v1_set_foveal_goal.argtypes = [FP, vp, vp, vp, FB, i64, vp]
+    lib.lmaze_expand_planes.restype = C.c_int
+    lib.lmaze_expand_planes.argtypes = [vp, i32, i32, i32, vp, i64, vp]
     if lib.lmaze_abi_version() != ABI_VERSION:
         raise ImportError("liblmaze_hip.so ABI %d != binding %d: rebuild" % (lib.lmaze_abi_version(), ABI_VERSION))
     return lib

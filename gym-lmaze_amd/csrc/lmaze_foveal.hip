@@ -1,0 +1,493 @@
+// lmaze_foveal.hip -- the foveal variants of the step path (5x5 window observations), gfx950.
+//
+//   v1 = gym_lmaze/envs/lmaze_env_v1.py:114-200   4-neighbour move, two reward streams, foveal goal
+//   v2 = gym_lmaze/envs/lmaze_env_v2.py:127-225   25-way teleport inside the fovea, 5 layouts
+//   v4 = gym_lmaze/envs/lmaze_env_v4.py:167-272   v2 + float visit-map plane (whole-plane halving)
+//
+// Same two-phase shape as lmaze_step.hip: one lane per env runs the transition against the
+// layout table held in LDS and leaves a small record (window centres, goal, layout row, action)
+// in LDS; then the workgroup's lanes stripe its contiguous observation range float[envs*C*25]
+// with 16-byte stores.  v4 adds a middle phase: the workgroup's visit maps float[envs*G*G] are
+// streamed through (load, +window, halve, store) with 16-byte accesses and kept in LDS for the
+// window samples.  HBM bytes per env-step: v1 436, v2 557, v4 3 349.
+#include "lmaze_common.h"
+
+namespace lmaze {
+
+constexpr int FOV = LMAZE_FOVEA;
+constexpr int W25 = FOV * FOV;
+
+enum FovealMode { FM_STEP = 0, FM_RESET = 1, FM_SETGOAL = 2 };
+
+struct FovealArgs {
+    LmazeFovealParams p;
+    LmazeFovealBuffers b;
+    const uint8_t* layouts;
+    const int32_t* action;  // step: action ids; setgoal: ij[N,2]
+    const uint8_t* mask;
+    int64_t n;
+    int32_t place;
+    uint64_t seed, epoch;
+    int64_t env_base;
+};
+
+struct EnvRec {           // what the render phase needs about one env
+    int16_t cx, cy;       // centre of the current window (ball after the move)
+    int16_t px, py;       // centre of the "previous" window
+    int16_t gx, gy;       // goal (v2/v4) or foveal goal (v1 local view)
+    int16_t lid;          // row of the layout table
+    int16_t action;       // v2/v4 action plane (-1: none); v1: 1 = local view, 0 = global view
+    int32_t skip;         // env untouched by this call: neither state nor obs are written
+    int32_t flat;         // v1 local view: flat index of the one-hot goal (numpy wrap applied), -1 none
+};
+
+__device__ __forceinline__ float free_plane(uint8_t c) { return (c == 'B' || c == 'S' || c == 'X') ? 1.0f : 0.0f; }
+
+__device__ __forceinline__ int channels_of(int variant) {
+    return variant == LMAZE_VARIANT_V1 ? 4 : (variant == LMAZE_VARIANT_V2 ? 5 : 7);
+}
+
+// k-th (row-major) interior cell the reference's rejection loops accept, or the count (k < 0).
+// kind 0: goal (v2:279: not 'W', not 'S'); kind 1: ball (v2:292: not 'W', not 'X', != goal)
+__device__ __forceinline__ int count_or_kth(const uint8_t* lay, int G, int kind, int goal_cell, int k) {
+    int cnt = 0;
+    for (int x = 1; x <= G - 2; ++x)
+        for (int y = 1; y <= G - 2; ++y) {
+            const uint8_t c = lay[x * G + y];
+            const bool ok = kind == 0 ? (c != 'W' && c != 'S') : (c != 'W' && c != 'X' && x * G + y != goal_cell);
+            if (ok) {
+                if (cnt == k) return x * G + y;
+                ++cnt;
+            }
+        }
+    return k < 0 ? cnt : -1;
+}
+
+// one observation element: channel ch, window cell (i, j) of env record r
+template <int VARIANT>
+__device__ __forceinline__ float obs_element(const EnvRec& r, const uint8_t* lays, const float* visit_tile, int G,
+                                             int ch, int i, int j) {
+    if (VARIANT == LMAZE_VARIANT_V1) {
+        const int x = r.cx - 2 + i, y = r.cy - 2 + j;
+        const bool in = x >= 0 && y >= 0 && x < G && y < G;
+        const uint8_t c = in ? lays[x * G + y] : (uint8_t)'W';
+        if (ch == 0) return (i == 2 && j == 2) ? 1.0f : 0.0f;                    // ball plane, v1:216
+        if (ch == 1) return (in && c == 'W') ? 1.0f : 0.0f;                      // wall, v1:70
+        if (ch == 2) return r.action ? ((in && x * G + y == r.flat) ? 1.0f : 0.0f)   // local goal, v1:244-245
+                                     : ((in && c == 'X') ? 1.0f : 0.0f);             // global goal, v1:74
+        return in ? free_plane(c) : 0.0f;                                        // free, v1:78
+    }
+    constexpr int PER = VARIANT == LMAZE_VARIANT_V4 ? 3 : 2;
+    if (ch == PER) return (r.action == i * FOV + j) ? 1.0f : 0.0f;               // action plane, v2:135-136
+    const bool prev = ch > PER;
+    const int plane = prev ? ch - PER - 1 : ch;
+    const int x = (prev ? r.px : r.cx) - 2 + i, y = (prev ? r.py : r.cy) - 2 + j;
+    const bool in = x >= 0 && y >= 0 && x < G && y < G;
+    if (plane == 0) return in ? free_plane(lays[r.lid * G * G + x * G + y]) : 0.0f;   // v2:94
+    if (plane == 1) return (x == r.gx && y == r.gy) ? 1.0f : 0.0f;                    // v2:95
+    return in ? visit_tile[x * G + y] : 0.0f;                                         // v4 visit map (live view)
+}
+
+template <int VARIANT, int MODE, int EPB>
+__global__ __launch_bounds__(LMAZE_BLOCK) void foveal_kernel(const FovealArgs a) {
+    constexpr bool V1 = VARIANT == LMAZE_VARIANT_V1, V4 = VARIANT == LMAZE_VARIANT_V4;
+    constexpr int C = V1 ? 4 : (V4 ? 7 : 5);
+    constexpr int PERENV = C * W25;  // floats of observation per env
+    const int G = a.p.grid, CELLS = G * G, L = V1 ? 1 : a.p.n_layouts;
+
+    extern __shared__ int4 lds4[];
+    EnvRec* rec = reinterpret_cast<EnvRec*>(lds4);                         // [EPB]
+    float* vtile = reinterpret_cast<float*>(rec + EPB);                    // [EPB*CELLS] (v4 only)
+    uint8_t* lays = reinterpret_cast<uint8_t*>(vtile + (V4 ? EPB * CELLS : 0));  // [L*CELLS]
+    __shared__ int any_skip;
+
+    const int tid = threadIdx.x;
+    const int64_t blockbase = (int64_t)blockIdx.x * EPB;
+    const int nb = (int)min((int64_t)EPB, a.n - blockbase);
+    if (tid == 0) any_skip = 0;
+    for (int i = tid; i < L * CELLS; i += LMAZE_BLOCK) lays[i] = a.layouts[i];
+    __syncthreads();
+
+    // ---------------- phase 1: one lane per env ----------------
+    for (int le = tid; le < nb; le += LMAZE_BLOCK) {
+        const int64_t e = blockbase + le;
+        EnvRec r;
+        r.skip = 0; r.flat = -1; r.action = -1; r.lid = 0; r.gx = r.gy = -9;
+        int bx = a.b.ball_xy[2 * e], by = a.b.ball_xy[2 * e + 1];
+        r.px = (int16_t)bx; r.py = (int16_t)by;
+        if (MODE != FM_STEP && a.mask && !a.mask[e]) r.skip = 1;
+        if (V1) {
+            int fgx = a.b.fgoal_xy[2 * e], fgy = a.b.fgoal_xy[2 * e + 1];
+            r.action = 1;  // local view unless this is a reset
+            if (MODE == FM_STEP) {
+                const int act = a.action[e];
+                const int sc = a.b.step_count[e] + 1;                  // v1:117
+                const int fsc = a.b.foveal_step_count[e] + 1;          // v1:118
+                float fr = -0.0f, rw = -0.0f;                          // v1:120-121
+                bool local_done = false;                               // v1:123
+                int ox, oy;
+                decode_action(act, ox, oy);                            // v1:125-133
+                const int tx = clampi(bx + ox, 0, G - 1), ty = clampi(by + oy, 0, G - 1);
+                const uint8_t c = lays[tx * G + ty];
+                if (c == 'W') {                                        // v1:135-138
+                    rw = a.p.reward_wall; fr = a.p.reward_wall;
+                } else if (c == 'B') {                                 // v1:140-163
+                    bx = tx; by = ty;
+                    rw = a.p.reward_move; fr = a.p.reward_move;
+                    if (bx < fgx - 1 || bx > fgx + 2 || by < fgy - 1 || by > fgy + 2) {
+                        local_done = true; fr = a.p.reward_wall;
+                    } else if (by == fgy && bx == fgx) {
+                        local_done = true; fr = a.p.reward_goal;
+                    }
+                } else if (c == 'X') {                                 // v1:165-183
+                    bx = tx; by = ty;
+                    rw = a.p.reward_goal;
+                    if (by == fgy && bx == fgx) { local_done = true; fr = a.p.reward_goal; }
+                    else fr = a.p.reward_move;
+                }
+                const bool done = (rw == a.p.reward_goal) || (sc == a.p.step_limit);                         // v1:294-304
+                const bool fdone = local_done || fr == a.p.reward_goal || fsc == a.p.foveal_step_limit || done;  // v1:308-324
+                a.b.ball_xy[2 * e] = bx; a.b.ball_xy[2 * e + 1] = by;
+                a.b.step_count[e] = sc; a.b.foveal_step_count[e] = fsc;
+                a.b.reward[e] = rw; a.b.foveal_reward[e] = fr;
+                a.b.done[e] = done ? 1 : 0; a.b.foveal_done[e] = fdone ? 1 : 0;
+            } else if (MODE == FM_RESET && !r.skip) {
+                if (a.place) {                                         // v1:82-84: ball = first 'S'
+                    for (int c = 0; c < CELLS; ++c)
+                        if (lays[c] == 'S') { bx = c / G; by = c % G; break; }
+                    a.b.ball_xy[2 * e] = bx; a.b.ball_xy[2 * e + 1] = by;
+                }
+                a.b.reward[e] = -0.0f; a.b.foveal_reward[e] = -0.0f;   // v1:90-91
+                a.b.step_count[e] = 0;                                 // v1:93 (fovealStepCount kept, v1:94)
+                a.b.done[e] = 0; a.b.foveal_done[e] = 0;
+                r.action = 0;                                          // v1:100 getGlobalView
+            } else if (MODE == FM_SETGOAL && !r.skip) {                // v1:104-110
+                fgx = bx + a.action[2 * e] - 2;
+                fgy = by + a.action[2 * e + 1] - 2;
+                a.b.fgoal_xy[2 * e] = fgx; a.b.fgoal_xy[2 * e + 1] = fgy;
+                a.b.foveal_step_count[e] = 0;
+            }
+            int flat = fgx * G + fgy;                                  // v1:244-245, numpy negative-index wrap
+            if (flat < 0) flat += CELLS;
+            r.flat = (flat >= 0 && flat < CELLS) ? flat : -1;
+        } else {
+            int lid = a.b.layout_id[e];
+            int gx = a.b.goal_xy[2 * e], gy = a.b.goal_xy[2 * e + 1];
+            if (MODE == FM_STEP) {
+                const int act = a.action[e];
+                if (act < 0 || act >= W25) {
+                    r.skip = 1;                                        // the reference raises before touching anything
+                } else {
+                    lid = clampi(lid, 0, L - 1);
+                    const uint8_t* lay = lays + lid * CELLS;
+                    float rw = -0.0f;                                  // v2:146
+                    const int sc = a.b.step_count[e] + 1;              // v2:147
+                    const int fx = bx + act / FOV - 2, fy = by + act % FOV - 2;   // v2:151-152
+                    if (fx < G - 2 && fx > 1 && fy < G - 2 && fy > 1) {           // v2:157-159
+                        bx = fx; by = fy;
+                    } else {                                           // v2:160-169
+                        if (fx >= G - 2) bx = G - 3;
+                        if (fx <= 1) bx = 2;
+                        if (fy >= G - 2) by = G - 3;
+                        if (fy <= 1) by = 2;
+                    }
+                    const bool fin = fx >= 0 && fy >= 0 && fx < G && fy < G;
+                    const uint8_t c = fin ? lay[fx * G + fy] : (uint8_t)'W';
+                    if (fx == gx && fy == gy) rw = a.p.reward_goal;    // v2:175-180
+                    else if (c == 'W') rw = a.p.reward_wall;
+                    else if (c == 'B' || c == 'S') rw = a.p.reward_move;
+                    a.b.ball_xy[2 * e] = bx; a.b.ball_xy[2 * e + 1] = by;
+                    a.b.step_count[e] = sc;
+                    a.b.reward[e] = rw;
+                    a.b.done[e] = (rw == a.p.reward_goal || sc > a.p.step_limit) ? 1 : 0;   // v2:222
+                    r.action = (int16_t)act;
+                }
+            } else if (MODE == FM_RESET && !r.skip) {
+                if (a.place) {
+                    const uint4 d = env_draw(a.seed, a.epoch, a.env_base + e);
+                    const int lid_new = (int)__umulhi(d.z, (uint32_t)L);
+                    if (V4) lid = lid_new;                             // v4:97 setGrid first
+                    lid = clampi(lid, 0, L - 1);
+                    const uint8_t* lay = lays + lid * CELLS;
+                    const int cg = count_or_kth(lay, G, 0, -1, -1);
+                    int goal_cell = -1;
+                    if (cg > 0) {
+                        goal_cell = count_or_kth(lay, G, 0, -1, (int)__umulhi(d.x, (uint32_t)cg));
+                        gx = goal_cell / G; gy = goal_cell % G;
+                        a.b.goal_xy[2 * e] = gx; a.b.goal_xy[2 * e + 1] = gy;
+                    }
+                    const int cb = count_or_kth(lay, G, 1, goal_cell, -1);
+                    if (cb > 0) {
+                        const int cell = count_or_kth(lay, G, 1, goal_cell, (int)__umulhi(d.y, (uint32_t)cb));
+                        bx = cell / G; by = cell % G;
+                        a.b.ball_xy[2 * e] = bx; a.b.ball_xy[2 * e + 1] = by;
+                    }
+                    lid = lid_new;                                     // v2:92 setGrid last
+                    a.b.layout_id[e] = lid;
+                }
+                a.b.reward[e] = -0.0f;                                 // v2:84
+                a.b.step_count[e] = 0;                                 // v2:86
+                a.b.done[e] = 0;
+                r.px = (int16_t)bx; r.py = (int16_t)by;                // v2:109: previous = current
+            }
+            r.lid = (int16_t)clampi(lid, 0, L - 1);
+            r.gx = (int16_t)gx; r.gy = (int16_t)gy;
+        }
+        r.cx = (int16_t)bx; r.cy = (int16_t)by;
+        rec[le] = r;
+        if (r.skip) any_skip = 1;
+    }
+    __syncthreads();
+    const bool some_skipped = any_skip != 0;
+
+    // ---------------- phase 2 (v4): stream the visit maps, v4:116-119 / v4:211-214 ----------------
+    if (V4) {
+        float* vis = a.b.visit + (size_t)blockbase * CELLS;
+        const int total = nb * CELLS;
+        if ((CELLS & 3) == 0) {  // a 16-byte access never straddles two envs
+            for (int q = tid; q < (total >> 2); q += LMAZE_BLOCK) {
+                const int f0 = q << 2;
+                const int le = f0 / CELLS;
+                const EnvRec r = rec[le];
+                const int c0 = f0 - le * CELLS;
+                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (r.skip || MODE == FM_STEP) v = reinterpret_cast<const float4*>(vis)[q];
+                if (!r.skip) {
+                    float* pv = reinterpret_cast<float*>(&v);
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        const int x = (c0 + k) / G, y = (c0 + k) - x * G;
+                        const float w = (x >= r.cx - 2 && x <= r.cx + 2 && y >= r.cy - 2 && y <= r.cy + 2) ? 1.0f : 0.0f;
+                        pv[k] = (pv[k] + w) * 0.5f;  // float32 add + exact halving == the reference's float64 round trip
+                    }
+                    reinterpret_cast<float4*>(vis)[q] = v;
+                }
+                reinterpret_cast<float4*>(vtile)[q] = v;
+            }
+        } else {
+            for (int f = tid; f < total; f += LMAZE_BLOCK) {
+                const int le = f / CELLS;
+                const EnvRec r = rec[le];
+                const int c = f - le * CELLS;
+                float v = (r.skip || MODE == FM_STEP) ? vis[f] : 0.0f;
+                if (!r.skip) {
+                    const int x = c / G, y = c - x * G;
+                    const float w = (x >= r.cx - 2 && x <= r.cx + 2 && y >= r.cy - 2 && y <= r.cy + 2) ? 1.0f : 0.0f;
+                    v = (v + w) * 0.5f;
+                    vis[f] = v;
+                }
+                vtile[f] = v;
+            }
+        }
+        __syncthreads();
+    }
+
+    // ---------------- phase 3: render float[nb*C*25], contiguous, 16-byte stores ----------------
+    float* obs = a.b.obs + (size_t)blockbase * PERENV;
+    const int R = nb * PERENV;
+    const int nq = some_skipped ? 0 : (R >> 2);
+    for (int q = tid; q < nq; q += LMAZE_BLOCK) {
+        int f = q << 2;
+        int le = f / PERENV;
+        int rem = f - le * PERENV;
+        float v[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int ch = rem / W25, cell = rem - ch * W25;
+            v[k] = obs_element<VARIANT>(rec[le], lays, vtile + le * CELLS, G, ch, cell / FOV, cell % FOV);
+            if (++rem == PERENV) { rem = 0; ++le; }
+        }
+        reinterpret_cast<float4*>(obs)[q] = make_float4(v[0], v[1], v[2], v[3]);
+    }
+    // scalar path: the ragged tail, or every element when some env of the workgroup is skipped
+    for (int f = (nq << 2) + tid; f < R; f += LMAZE_BLOCK) {
+        const int le = f / PERENV;
+        if (rec[le].skip) continue;
+        const int rem = f - le * PERENV;
+        const int ch = rem / W25, cell = rem - ch * W25;
+        obs[f] = obs_element<VARIANT>(rec[le], lays, vtile + le * CELLS, G, ch, cell / FOV, cell % FOV);
+    }
+}
+
+// ------------------------------------------------------------------------------------
+// xE nearest-neighbour on float planes (v1:258-277, v2:197-203): one workgroup per env
+// ------------------------------------------------------------------------------------
+struct ExpandPlanesArgs {
+    const float* planes;
+    float* out;
+    int64_t n;
+    int32_t channels, g, expansion;
+};
+
+__global__ __launch_bounds__(LMAZE_BLOCK) void expand_planes_kernel(const ExpandPlanesArgs a) {
+    extern __shared__ int4 lds4[];
+    const int g = a.g, E = a.expansion, C = a.channels;
+    const int PC = g * g, S = g * E, PLANE = S * S, L = C * PLANE;
+    float* src = reinterpret_cast<float*>(lds4);                    // [C*g*g]
+    uint16_t* rowmap = reinterpret_cast<uint16_t*>(src + C * PC);   // [S] row -> (row / E) * g
+    uint16_t* colmap = rowmap + S;                                  // [S] col -> col / E
+    const int tid = threadIdx.x;
+    for (int64_t i = blockIdx.x; i < a.n; i += gridDim.x) {
+        __syncthreads();
+        for (int k = tid; k < C * PC; k += LMAZE_BLOCK) src[k] = a.planes[(size_t)i * C * PC + k];
+        for (int k = tid; k < S; k += LMAZE_BLOCK) {
+            rowmap[k] = (uint16_t)((k / E) * g);
+            colmap[k] = (uint16_t)(k / E);
+        }
+        __syncthreads();
+        const size_t B = (size_t)i * L;
+        const size_t a0 = (B + 3) & ~(size_t)3, a1 = (B + L) & ~(size_t)3;
+        auto value = [&](int local) -> float {
+            const int c = local / PLANE;
+            const int rem = local - c * PLANE;
+            const int row = rem / S, col = rem - row * S;
+            return src[c * PC + rowmap[row] + colmap[col]];
+        };
+        if (tid < (int)(a0 - B)) a.out[B + tid] = value(tid);
+        if (tid < (int)(B + L - a1)) a.out[a1 + tid] = value((int)(a1 - B) + tid);
+        const int nq = (int)((a1 - a0) >> 2);
+        float4* out4 = reinterpret_cast<float4*>(a.out + a0);
+        const int head = (int)(a0 - B);
+        for (int q = tid; q < nq; q += LMAZE_BLOCK) {
+            const int local = head + (q << 2);
+            int c = local / PLANE;
+            int rem = local - c * PLANE;
+            int row = rem / S, col = rem - row * S;
+            float v[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                v[j] = src[c * PC + rowmap[row] + colmap[col]];
+                if (++col == S) {
+                    col = 0;
+                    if (++row == S) { row = 0; ++c; }
+                }
+            }
+            out4[q] = make_float4(v[0], v[1], v[2], v[3]);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------
+// host side
+// ------------------------------------------------------------------------------------
+template <int VARIANT, int MODE, int EPB>
+static hipError_t launch_foveal_one(const FovealArgs& a, hipStream_t s) {
+    const int cells = a.p.grid * a.p.grid;
+    const int L = VARIANT == LMAZE_VARIANT_V1 ? 1 : a.p.n_layouts;
+    size_t lds = sizeof(EnvRec) * EPB + (size_t)((L * cells + 15) & ~15);
+    if (VARIANT == LMAZE_VARIANT_V4) lds += (size_t)EPB * cells * 4;
+    const int64_t blocks = (a.n + EPB - 1) / EPB;
+    hipLaunchKernelGGL((foveal_kernel<VARIANT, MODE, EPB>), dim3((unsigned)blocks), dim3(LMAZE_BLOCK), lds, s, a);
+    return hipGetLastError();
+}
+
+template <int MODE>
+static hipError_t launch_foveal_mode(const FovealArgs& a, hipStream_t s) {
+    if (a.n == 0) return hipSuccess;
+    switch (a.p.variant) {
+        case LMAZE_VARIANT_V1: return launch_foveal_one<LMAZE_VARIANT_V1, MODE, 256>(a, s);
+        case LMAZE_VARIANT_V2: return launch_foveal_one<LMAZE_VARIANT_V2, MODE, 256>(a, s);
+        default:
+            // v4 tiles the workgroup's visit maps in LDS: 32 envs of 18x18 floats = 41 KiB
+            if (a.p.grid * a.p.grid * 4 * 32 <= 96 * 1024) return launch_foveal_one<LMAZE_VARIANT_V4, MODE, 32>(a, s);
+            return launch_foveal_one<LMAZE_VARIANT_V4, MODE, 8>(a, s);
+    }
+}
+
+static int check_foveal(const LmazeFovealParams* p, const uint8_t* layouts, const LmazeFovealBuffers* b, int64_t n) {
+    if (!p || !layouts || !b) return LMAZE_E_NULL;
+    if (p->variant != LMAZE_VARIANT_V1 && p->variant != LMAZE_VARIANT_V2 && p->variant != LMAZE_VARIANT_V4)
+        return LMAZE_E_VARIANT;
+    if (p->grid < FOV || p->grid > LMAZE_MAX_GRID) return LMAZE_E_GRID;
+    if (p->n_layouts < 1 || p->n_layouts > LMAZE_MAX_LAYOUTS) return LMAZE_E_LAYOUT;
+    if (n < 0 || n > ((int64_t)1 << 40)) return LMAZE_E_COUNT;
+    if (!b->ball_xy || !b->step_count || !b->reward || !b->done || !b->obs) return LMAZE_E_NULL;
+    if (p->variant == LMAZE_VARIANT_V1 && (!b->fgoal_xy || !b->foveal_step_count || !b->foveal_reward || !b->foveal_done))
+        return LMAZE_E_NULL;
+    if (p->variant != LMAZE_VARIANT_V1 && (!b->goal_xy || !b->layout_id)) return LMAZE_E_NULL;
+    if (p->variant == LMAZE_VARIANT_V4 && !b->visit) return LMAZE_E_NULL;
+    if (((uintptr_t)b->obs & 15) || (b->visit && ((uintptr_t)b->visit & 15))) return LMAZE_E_ALIGN;
+    return 0;
+}
+
+static FovealArgs make_foveal_args(const LmazeFovealParams* p, const uint8_t* layouts, const LmazeFovealBuffers* b, int64_t n) {
+    FovealArgs a;
+    a.p = *p;
+    a.b = *b;
+    a.layouts = layouts;
+    a.action = nullptr;
+    a.mask = nullptr;
+    a.n = n;
+    a.place = 0;
+    a.seed = 0;
+    a.epoch = 0;
+    a.env_base = 0;
+    return a;
+}
+
+}  // namespace lmaze
+
+using namespace lmaze;
+
+extern "C" {
+
+int lmaze_foveal_step(const LmazeFovealParams* params, const uint8_t* layouts, const int32_t* action,
+                      const LmazeFovealBuffers* bufs, int64_t n, void* stream) {
+    int rc = check_foveal(params, layouts, bufs, n);
+    if (rc) return rc;
+    if (!action) return LMAZE_E_NULL;
+    FovealArgs a = make_foveal_args(params, layouts, bufs, n);
+    a.action = action;
+    return (int)launch_foveal_mode<FM_STEP>(a, (hipStream_t)stream);
+}
+
+int lmaze_foveal_reset(const LmazeFovealParams* params, const uint8_t* layouts, const uint8_t* mask, int32_t place,
+                       uint64_t seed, uint64_t epoch, int64_t env_base, const LmazeFovealBuffers* bufs, int64_t n,
+                       void* stream) {
+    int rc = check_foveal(params, layouts, bufs, n);
+    if (rc) return rc;
+    FovealArgs a = make_foveal_args(params, layouts, bufs, n);
+    a.mask = mask;
+    a.place = place;
+    a.seed = seed;
+    a.epoch = epoch;
+    a.env_base = env_base;
+    return (int)launch_foveal_mode<FM_RESET>(a, (hipStream_t)stream);
+}
+
+int lmaze_v1_set_foveal_goal(const LmazeFovealParams* params, const uint8_t* layouts, const int32_t* ij,
+                             const uint8_t* mask, const LmazeFovealBuffers* bufs, int64_t n, void* stream) {
+    int rc = check_foveal(params, layouts, bufs, n);
+    if (rc) return rc;
+    if (params->variant != LMAZE_VARIANT_V1) return LMAZE_E_VARIANT;
+    if (!ij) return LMAZE_E_NULL;
+    FovealArgs a = make_foveal_args(params, layouts, bufs, n);
+    a.action = ij;
+    a.mask = mask;
+    if (n == 0) return 0;
+    return (int)launch_foveal_one<LMAZE_VARIANT_V1, FM_SETGOAL, 256>(a, (hipStream_t)stream);
+}
+
+int lmaze_expand_planes(const float* planes, int32_t channels, int32_t g, int32_t expansion, float* out, int64_t n,
+                        void* stream) {
+    if (!planes || !out) return LMAZE_E_NULL;
+    if (g < 1 || g > LMAZE_MAX_GRID) return LMAZE_E_GRID;
+    if (expansion < 1 || expansion > 16 || channels < 1 || channels > 16) return LMAZE_E_EXPANSION;
+    if (n < 0 || n > ((int64_t)1 << 40)) return LMAZE_E_COUNT;
+    if (((uintptr_t)out & 15) || ((uintptr_t)planes & 3)) return LMAZE_E_ALIGN;
+    if (n == 0) return 0;
+    ExpandPlanesArgs a;
+    a.planes = planes;
+    a.out = out;
+    a.n = n;
+    a.channels = channels;
+    a.g = g;
+    a.expansion = expansion;
+    const int S = g * expansion;
+    const size_t lds = (((size_t)channels * g * g * 4 + (size_t)S * 4) + 15) & ~(size_t)15;
+    const unsigned blocks = (unsigned)(n < 65536 ? n : 65536);
+    hipLaunchKernelGGL(expand_planes_kernel, dim3(blocks), dim3(LMAZE_BLOCK), lds, (hipStream_t)stream, a);
+    return (int)hipGetLastError();
+}
+
+}  // extern "C"

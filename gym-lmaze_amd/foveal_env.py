@@ -1,0 +1,200 @@
+"""LmazeFovealVecEnv: N envs of the foveal variants (v1, v2, v4) as struct-of-arrays torch
+tensors in HBM, stepped by one HIP kernel per step() through lmaze_foveal_* (include/lmaze.h).
+
+Host side only (buffers, marshalling, stream); the transition, the visit-map update and the
+5x5 window render run in liblmaze_hip.so.  Reference: gym_lmaze/envs/lmaze_env_v1.py,
+lmaze_env_v2.py, lmaze_env_v4.py.
+"""
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import _abi
+from . import layouts as L
+from .vec_env import _align, resolve_device
+
+FOVEAL_VARIANTS = {
+    # lmaze_env_v1.py:21-36
+    "v1": dict(id=_abi.VARIANT_V1, layouts=(L.V1_GRID_14,), channels=4, expansion=7, step_limit=200,
+               foveal_step_limit=10, rewards=(-1.0, 0.01, 1.0), n_actions=4),
+    # lmaze_env_v2.py:26-49
+    "v2": dict(id=_abi.VARIANT_V2, layouts=L.FOVEAL_GRIDS_18, channels=5, expansion=7, step_limit=50,
+               foveal_step_limit=0, rewards=(-1.0, -0.01, 100.0), n_actions=25),
+    # lmaze_env_v4.py:23-48
+    "v4": dict(id=_abi.VARIANT_V4, layouts=L.FOVEAL_GRIDS_18, channels=7, expansion=7, step_limit=50,
+               foveal_step_limit=0, rewards=(-1.0, -0.01, 100.0), n_actions=25),
+}
+
+
+class LmazeFovealVecEnv(object):
+    """N foveal mazes.  obs is float32[N,C,5,5] -- the reference's retState before its x7 loop;
+    expanded() gives the (C,35,35) reference layout."""
+
+    def __init__(self, num_envs, variant="v2", layouts=None, device=None, seed=0, env_base=0, reset=True):
+        if variant not in FOVEAL_VARIANTS:
+            raise ValueError("unknown foveal variant %r (have %s)" % (variant, sorted(FOVEAL_VARIANTS)))
+        spec = FOVEAL_VARIANTS[variant]
+        self.variant = variant
+        self.num_envs = N = int(num_envs)
+        if N < 1:
+            raise ValueError("num_envs must be >= 1")
+        self.device = resolve_device(device)
+        self.channels = spec["channels"]
+        self.expansion = spec["expansion"]
+        self.seed, self.env_base, self._epoch = int(seed), int(env_base), 0
+        tabs = [L.to_codes(t) for t in (layouts if layouts is not None else spec["layouts"])]
+        G = tabs[0].shape[0]
+        pad = 2 if variant == "v1" else 2   # the 5x5 window must stay inside the array
+        for t in tabs:
+            if t.shape != (G, G):
+                raise ValueError("all layouts must share one square shape")
+            L.validate(t, need_goal_marker=(variant == "v1"))
+            W = ord("W")
+            if not ((t[:pad] == W).all() and (t[-pad:] == W).all() and (t[:, :pad] == W).all() and (t[:, -pad:] == W).all()):
+                raise ValueError("foveal layouts need a %d-cell 'W' padding (lmaze_env_v1.py:40-53)" % pad)
+        if variant == "v1" and len(tabs) != 1:
+            raise ValueError("v1 has a single layout")
+        self.grid = G
+        self.n_layouts = len(tabs)
+        self.layouts = torch.from_numpy(np.stack(tabs).copy()).to(self.device)
+
+        sizes = [("ball_xy", 8 * N), ("goal_xy", 8 * N), ("fgoal_xy", 8 * N), ("layout_id", 4 * N),
+                 ("step_count", 4 * N), ("foveal_step_count", 4 * N), ("reward", 4 * N), ("foveal_reward", 4 * N),
+                 ("done", N), ("foveal_done", N)]
+        offs, total = {}, 0
+        for name, sz in sizes:
+            offs[name] = total
+            total += _align(sz)
+        self._state = torch.zeros(total, dtype=torch.uint8, device=self.device)
+
+        def view(name, nbytes, dtype, shape):
+            return self._state[offs[name]:offs[name] + nbytes].view(dtype).view(shape)
+
+        self.ball_xy = view("ball_xy", 8 * N, torch.int32, (N, 2))
+        self.goal_xy = view("goal_xy", 8 * N, torch.int32, (N, 2))
+        self.fgoal_xy = view("fgoal_xy", 8 * N, torch.int32, (N, 2))
+        self.layout_id = view("layout_id", 4 * N, torch.int32, (N,))
+        self.step_count = view("step_count", 4 * N, torch.int32, (N,))
+        self.foveal_step_count = view("foveal_step_count", 4 * N, torch.int32, (N,))
+        self.reward = view("reward", 4 * N, torch.float32, (N,))
+        self.foveal_reward = view("foveal_reward", 4 * N, torch.float32, (N,))
+        self._done_u8 = view("done", N, torch.uint8, (N,))
+        self._fdone_u8 = view("foveal_done", N, torch.uint8, (N,))
+        self.done = self._done_u8.view(torch.bool)
+        self.foveal_done = self._fdone_u8.view(torch.bool)
+        self.visit = torch.zeros((N, G, G), dtype=torch.float32, device=self.device) if variant == "v4" else None
+        self.obs = torch.zeros((N, self.channels, _abi.FOVEA, _abi.FOVEA), dtype=torch.float32, device=self.device)
+        self._expanded = None
+        self._names = sizes
+
+        r = spec["rewards"]
+        self.params = _abi.LmazeFovealParams(spec["id"], G, self.n_layouts, spec["step_limit"],
+                                             spec["foveal_step_limit"], r[0], r[1], r[2])
+        self._pp = C.byref(self.params)
+        self.bufs = _abi.LmazeFovealBuffers(
+            self.ball_xy.data_ptr(), self.goal_xy.data_ptr(), self.fgoal_xy.data_ptr(), self.layout_id.data_ptr(),
+            self.step_count.data_ptr(), self.foveal_step_count.data_ptr(), self.reward.data_ptr(),
+            self.foveal_reward.data_ptr(), self._done_u8.data_ptr(), self._fdone_u8.data_ptr(),
+            self.visit.data_ptr() if self.visit is not None else None, self.obs.data_ptr())
+        self._pb = C.byref(self.bufs)
+        self._p_layouts = self.layouts.data_ptr()
+        if variant == "v1":
+            # goal = the 'X' cell (lmaze_env_v1.py:86-88); kept for the drop-in attributes
+            c = int(np.flatnonzero(tabs[0].reshape(-1) == ord("X"))[0])
+            self.goal_xy.copy_(torch.tensor([[c // G, c % G]], dtype=torch.int32).expand(N, 2))
+        if reset:
+            self.reset()
+
+    # ------------------------------------------------------------------ plumbing
+    def _stream(self):
+        return torch.cuda.current_stream(self.device).cuda_stream
+
+    def _guard(self):
+        return torch.cuda.device(self.device)
+
+    def _as_i32(self, x, numel):
+        if isinstance(x, torch.Tensor):
+            t = x.to(device=self.device, dtype=torch.int32)
+        else:
+            t = torch.as_tensor(np.asarray(x, dtype=np.int64).astype(np.int32), device=self.device)
+        t = t.reshape(-1).contiguous()
+        if t.numel() != numel:
+            raise ValueError("expected %d values, got %d" % (numel, t.numel()))
+        return t
+
+    def _mask_ptr(self, mask):
+        if mask is None:
+            return None, None
+        m = mask if isinstance(mask, torch.Tensor) else torch.as_tensor(np.asarray(mask), device=self.device)
+        m = m.to(device=self.device)
+        m = (m.view(torch.uint8) if m.dtype == torch.bool else (m != 0).to(torch.uint8)).contiguous()
+        if m.numel() != self.num_envs:
+            raise ValueError("mask must have %d entries" % self.num_envs)
+        return m, m.data_ptr()
+
+    # ------------------------------------------------------------------ the path
+    def step(self, actions):
+        """v1: ids 0..3 (else no move); v2/v4: 0..24 = 5*row+col of the target cell in the window.
+        Returns (obs, reward, done, actions); v1's second stream is in foveal_reward / foveal_done."""
+        a = self._as_i32(actions, self.num_envs)
+        with self._guard():
+            rc = _abi.lib.lmaze_foveal_step(self._pp, self._p_layouts, a.data_ptr(), self._pb, self.num_envs,
+                                            self._stream())
+        _abi.check("lmaze_foveal_step", rc)
+        return self.obs, self.reward, self.done, actions
+
+    def reset(self, mask=None, place=True, seed=None):
+        """Masked reset; place=False keeps the caller's ball/goal/layout_id (set_state)."""
+        if seed is not None:
+            self.seed, self._epoch = int(seed), 0
+        m, m_ptr = self._mask_ptr(mask)
+        with self._guard():
+            rc = _abi.lib.lmaze_foveal_reset(self._pp, self._p_layouts, m_ptr, 1 if place else 0,
+                                             self.seed & (2 ** 64 - 1), self._epoch, self.env_base, self._pb,
+                                             self.num_envs, self._stream())
+        _abi.check("lmaze_foveal_reset", rc)
+        self._epoch += 1
+        return self.obs
+
+    def set_foveal_goal(self, ij, mask=None):
+        """v1 setFovealGoal(i, j) (lmaze_env_v1.py:104-110); ij int[N,2]."""
+        t = self._as_i32(ij, 2 * self.num_envs)
+        m, m_ptr = self._mask_ptr(mask)
+        with self._guard():
+            rc = _abi.lib.lmaze_v1_set_foveal_goal(self._pp, self._p_layouts, t.data_ptr(), m_ptr, self._pb,
+                                                   self.num_envs, self._stream())
+        _abi.check("lmaze_v1_set_foveal_goal", rc)
+        return self.obs
+
+    def set_state(self, **kw):
+        for name, src in kw.items():
+            dst = {"done": self._done_u8, "foveal_done": self._fdone_u8}.get(name, getattr(self, name))
+            t = src if isinstance(src, torch.Tensor) else torch.as_tensor(np.asarray(src))
+            dst.copy_(t.to(device=self.device).to(dst.dtype).reshape(dst.shape))
+
+    def expanded(self, out=None):
+        """(C, 5E, 5E) reference layout of the current obs (the x7 loop, lmaze_env_v2.py:197-203)."""
+        N, Cn, E = self.num_envs, self.channels, self.expansion
+        if out is None:
+            if self._expanded is None:
+                self._expanded = torch.empty((N, Cn, 5 * E, 5 * E), dtype=torch.float32, device=self.device)
+            out = self._expanded
+        with self._guard():
+            rc = _abi.lib.lmaze_expand_planes(self.obs.data_ptr(), Cn, _abi.FOVEA, E, out.data_ptr(), N, self._stream())
+        _abi.check("lmaze_expand_planes", rc)
+        return out
+
+    def host_state(self):
+        h = self._state.cpu().numpy()
+        base = self._state.data_ptr()
+        out = {}
+        for name, t, dt in (("ball_xy", self.ball_xy, np.int32), ("goal_xy", self.goal_xy, np.int32),
+                            ("fgoal_xy", self.fgoal_xy, np.int32), ("layout_id", self.layout_id, np.int32),
+                            ("step_count", self.step_count, np.int32),
+                            ("foveal_step_count", self.foveal_step_count, np.int32),
+                            ("reward", self.reward, np.float32), ("foveal_reward", self.foveal_reward, np.float32),
+                            ("done", self._done_u8, np.uint8), ("foveal_done", self._fdone_u8, np.uint8)):
+            off = t.data_ptr() - base
+            out[name] = h[off:off + t.numel() * t.element_size()].view(dt).reshape(tuple(t.shape))
+        return out

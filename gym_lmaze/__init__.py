@@ -21,7 +21,10 @@ registered_ids = _impl.registered_ids
 
 _ENTRY_POINTS = {
     "lmaze-v0": "gym_lmaze.envs:LmazeEnv",
+    "lmaze-v1": "gym_lmaze.envs:LmazeEnv_v1",
+    "lmaze-v2": "gym_lmaze.envs:LmazeEnv_v2",
     "lmaze-v3": "gym_lmaze.envs:LmazeEnv_v3",
+    "lmaze-v4": "gym_lmaze.envs:LmazeEnv_v4",
 }
 for _id, _ep in _ENTRY_POINTS.items():
     _impl.register(_id, _ep)

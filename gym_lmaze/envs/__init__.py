@@ -4,3 +4,6 @@ import importlib
 _impl = importlib.import_module("gym-lmaze_amd")
 LmazeEnv = _impl.LmazeEnv
 LmazeEnv_v3 = _impl.LmazeEnv_v3
+LmazeEnv_v1 = _impl.LmazeEnv_v1
+LmazeEnv_v2 = _impl.LmazeEnv_v2
+LmazeEnv_v4 = _impl.LmazeEnv_v4

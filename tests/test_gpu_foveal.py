@@ -1,0 +1,260 @@
+"""GPU: foveal variants (v1, v2, v4) through the C ABI against the reference fixtures and the
+C oracle.  Bit-exact: integers and float32 bit patterns (rewards incl. -0.0, visit map, planes)."""
+import importlib
+
+import numpy as np
+import pytest
+import torch
+
+import oracle_lib as O
+from conftest import golden_files
+from helpers import f32_bits, load_golden, obs_hash, ref_reward_bits
+
+pytestmark = pytest.mark.gpu
+
+PKG = importlib.import_module("gym-lmaze_amd")
+VID = {"v1": O.VARIANT_V1, "v2": O.VARIANT_V2, "v4": O.VARIANT_V4}
+
+
+def _np(t):
+    return t.detach().cpu().numpy()
+
+
+def _bits(a):
+    return np.ascontiguousarray(a, dtype=np.float32).view(np.uint32)
+
+
+# ---------------------------------------------------------------- fixtures (N = 1)
+def _replay_v24(g, variant):
+    env = PKG.LmazeFovealVecEnv(1, variant=variant, layouts=list(g["layouts"]))
+    E = int(g["E"])
+    n_reset = 0
+    for t in range(len(g["actions"])):
+        if g["reset_before"][t]:
+            env.set_state(ball_xy=g["ball_before"][t:t + 1], goal_xy=g["goal_before"][t:t + 1],
+                          layout_id=g["layout_id"][t:t + 1])
+            obs = _np(env.reset(place=False))
+            assert (_bits(obs[0]) == _bits(g["reset_planes"][n_reset])).all()
+            assert obs_hash(_np(env.expanded())[0]) == g["reset_hash"][n_reset]
+            n_reset += 1
+        obs, _, _, _ = env.step(g["actions"][t:t + 1])
+        h = env.host_state()
+        assert f32_bits(h["reward"])[0] == ref_reward_bits(g["reward"][t]), t
+        assert h["done"][0] == g["done"][t] and h["step_count"][0] == g["step_count"][t], t
+        assert tuple(h["ball_xy"][0]) == tuple(g["ball"][t]), t
+        assert (_bits(_np(obs)[0]) == _bits(g["planes"][t])).all(), t
+        assert obs_hash(_np(env.expanded())[0]) == g["obs_hash"][t], t
+
+
+@pytest.mark.parametrize("name", golden_files("v2_"))
+def test_hip_v2_matches_reference_fixture(name):
+    _replay_v24(load_golden(name), "v2")
+
+
+@pytest.mark.parametrize("name", golden_files("v4_"))
+def test_hip_v4_matches_reference_fixture(name):
+    _replay_v24(load_golden(name), "v4")
+
+
+@pytest.mark.parametrize("name", golden_files("v1_"))
+def test_hip_v1_matches_reference_fixture(name):
+    g = load_golden(name)
+    env = PKG.LmazeFovealVecEnv(1, variant="v1", layouts=[g["layout"]], reset=False)
+    E = int(g["E"])
+    n_reset = 0
+    for t in range(len(g["actions"])):
+        if g["reset_before"][t]:
+            obs = _np(env.reset())
+            assert (_bits(obs[0]) == _bits(g["reset_planes"][n_reset])).all()
+            assert obs_hash(_np(env.expanded())[0]) == g["reset_hash"][n_reset]
+            n_reset += 1
+        if g["setgoal_before"][t]:
+            obs = _np(env.set_foveal_goal(g["setgoal_ij"][t:t + 1]))
+            assert (_bits(obs[0]) == _bits(g["setgoal_planes"][t])).all(), t
+        h = env.host_state()
+        assert tuple(h["fgoal_xy"][0]) == tuple(g["fgoal_before"][t]) and h["foveal_step_count"][0] == g["fstep_before"][t]
+        obs, _, _, _ = env.step(g["actions"][t:t + 1])
+        h = env.host_state()
+        assert f32_bits(h["reward"])[0] == ref_reward_bits(g["reward"][t]), t
+        assert f32_bits(h["foveal_reward"])[0] == ref_reward_bits(g["foveal_reward"][t]), t
+        assert h["done"][0] == g["done"][t] and h["foveal_done"][0] == g["foveal_done"][t], t
+        assert h["step_count"][0] == g["step_count"][t] and h["foveal_step_count"][0] == g["foveal_step_count"][t], t
+        assert tuple(h["ball_xy"][0]) == tuple(g["ball"][t]), t
+        assert (_bits(_np(obs)[0]) == _bits(g["planes"][t])).all(), t
+        assert obs_hash(_np(env.expanded())[0]) == g["obs_hash"][t], t
+    assert tuple(_np(env.goal_xy)[0]) == tuple(g["goal"])
+
+
+# ---------------------------------------------------------------- batched vs oracle
+def _mirror(env, variant):
+    """An oracle-side copy of the env's state."""
+    st = O.FovealState(VID[variant], env.num_envs, env.grid)
+    h = env.host_state()
+    for k in ("ball_xy", "goal_xy", "fgoal_xy", "layout_id", "step_count", "foveal_step_count", "reward",
+              "foveal_reward", "done", "foveal_done"):
+        getattr(st, k)[...] = h[k]
+    if env.visit is not None:
+        st.visit[...] = _np(env.visit)
+    st.obs[...] = _np(env.obs)
+    return st
+
+
+def _assert_same(env, st, variant, t):
+    h = env.host_state()
+    keys = ["ball_xy", "step_count", "done"] + (["fgoal_xy", "foveal_step_count", "foveal_done"] if variant == "v1"
+                                                else ["goal_xy", "layout_id"])
+    for k in keys:
+        assert (h[k] == getattr(st, k)).all(), (k, t)
+    assert (f32_bits(h["reward"]) == f32_bits(st.reward)).all(), t
+    if variant == "v1":
+        assert (f32_bits(h["foveal_reward"]) == f32_bits(st.foveal_reward)).all(), t
+    if variant == "v4":
+        assert (_bits(_np(env.visit)) == _bits(st.visit)).all(), t
+    assert (_bits(_np(env.obs)) == _bits(st.obs)).all(), t
+
+
+@pytest.mark.parametrize("variant", ["v1", "v2", "v4"])
+@pytest.mark.parametrize("N", [1, 31, 257, 5000])
+def test_batched_rollout_with_masked_resets(variant, N):
+    seed = 100 + N
+    env = PKG.LmazeFovealVecEnv(N, variant=variant, seed=seed, env_base=5)
+    lay = _np(env.layouts)
+    p = O.foveal_params(VID[variant], env.grid, env.n_layouts)
+    # the constructor ran reset epoch 0 on a zero state: replay it in the oracle
+    st = O.FovealState(VID[variant], N, env.grid)
+    O.foveal_reset(p, lay, None, 1, seed, 0, st, env_base=5)
+    _assert_same(env, st, variant, "reset")
+    rs = np.random.RandomState(N)
+    epoch = 1
+    for t in range(70):
+        if variant == "v1":
+            a = np.where(rs.rand(N) < 0.9, rs.randint(0, 4, N), rs.randint(-1, 6, N)).astype(np.int32)
+            if t % 7 == 0:      # new foveal goals for the envs whose foveal episode ended
+                ij = rs.randint(0, 5, (N, 2)).astype(np.int32)
+                m = _np(env.foveal_done).astype(np.uint8) if t else np.ones(N, np.uint8)
+                env.set_foveal_goal(ij, mask=torch.from_numpy(m))
+                O.v1_set_foveal_goal(p, lay, ij, m, st)
+                _assert_same(env, st, variant, ("setgoal", t))
+        else:
+            a = np.where(rs.rand(N) < 0.95, rs.randint(0, 25, N), rs.randint(-3, 30, N)).astype(np.int32)
+        env.step(torch.from_numpy(a))
+        O.foveal_step(p, lay, a, st)
+        _assert_same(env, st, variant, t)
+        if t % 9 == 8:          # masked reset of the finished envs, device placement
+            m = st.done.copy()
+            env.reset(mask=torch.from_numpy(m))
+            O.foveal_reset(p, lay, m, 1, seed, epoch, st, env_base=5)
+            epoch += 1
+            _assert_same(env, st, variant, ("reset", t))
+    assert st.done.sum() >= 0
+
+
+@pytest.mark.parametrize("variant", ["v2", "v4"])
+def test_reset_placement_rules(variant):
+    """goal never on 'W'/'S', ball never on 'W'/'X'/goal, every layout row used."""
+    N = 1 << 15
+    env = PKG.LmazeFovealVecEnv(N, variant=variant, seed=3)
+    env.reset()                       # a second reset: v2 now places on the layouts drawn by the first
+    h = env.host_state()
+    lay = _np(env.layouts)
+    G = env.grid
+    lid_prev = None
+    if variant == "v2":               # v2 draws goal/ball on the layout it had BEFORE this reset (lmaze_env_v2.py:90-92)
+        env2 = PKG.LmazeFovealVecEnv(N, variant=variant, seed=3)
+        lid_prev = env2.host_state()["layout_id"]
+    lid = lid_prev if lid_prev is not None else h["layout_id"]
+    gc = lay[lid, h["goal_xy"][:, 0], h["goal_xy"][:, 1]]
+    bc = lay[lid, h["ball_xy"][:, 0], h["ball_xy"][:, 1]]
+    assert not np.isin(gc, [ord("W"), ord("S")]).any()
+    assert not np.isin(bc, [ord("W"), ord("X")]).any()
+    assert not (h["goal_xy"] == h["ball_xy"]).all(axis=1).any()
+    assert set(np.unique(h["layout_id"])) == set(range(5))
+    assert (h["step_count"] == 0).all() and (f32_bits(h["reward"]) == f32_bits(np.float32(-0.0))).all()
+
+
+@pytest.mark.parametrize("C,g,E", [(4, 5, 7), (5, 5, 7), (7, 5, 7), (3, 4, 3), (1, 5, 1), (16, 5, 2)])
+def test_expand_planes_matches_oracle(C, g, E):
+    abi = importlib.import_module("gym-lmaze_amd._abi")
+    N = 19
+    planes = np.random.RandomState(C * g * E).rand(N, C, g, g).astype(np.float32)
+    ref = O.expand_planes(planes, E)
+    d = torch.from_numpy(planes).cuda()
+    out = torch.full((N, C, g * E, g * E), -1.0, dtype=torch.float32, device="cuda")
+    rc = abi.lib.lmaze_expand_planes(d.data_ptr(), C, g, E, out.data_ptr(), N, torch.cuda.current_stream().cuda_stream)
+    assert rc == 0
+    assert (_bits(_np(out)) == _bits(ref)).all()
+
+
+def test_v4_visit_map_saturates_and_halves():
+    """Known answers: 0.5 after reset, 0.75 after one stay, -> 1.0; cells that
+    leave the window halve."""
+    env = PKG.LmazeFovealVecEnv(1, variant="v4", seed=1)
+    env.set_state(ball_xy=[[8, 8]], goal_xy=[[4, 4]], layout_id=[0])
+    env.reset(place=False)
+    v = _np(env.visit)[0]
+    assert v[8, 8] == 0.5 and v[6, 6] == 0.5 and v[5, 5] == 0.0
+    obs, _, _, _ = env.step([12])                      # centre cell: stay
+    v = _np(env.visit)[0]
+    assert v[8, 8] == 0.75
+    o = _np(obs)[0]
+    assert o[2, 2, 2] == 0.75 and o[6, 2, 2] == 0.75   # "previous" plane is a live view (Appendix B-7)
+    for _ in range(40):
+        env.step([12])
+    assert _np(env.visit)[0][8, 8] == 1.0
+    env.step([14])                                     # move right by 2: column 6 leaves the window
+    v = _np(env.visit)[0]
+    assert v[8, 6] == 0.5 and v[8, 10] == 1.0 and v[8, 12] == 0.5
+
+
+# ---------------------------------------------------------------- drop-in classes (reference-typed)
+def test_dropin_v2_and_v4_seeded_like_the_reference():
+    """random.seed/np.random.seed + the reference's own draw order => the fixture's placements."""
+    import random
+    import gym_lmaze
+    for vid in ("v2", "v4"):
+        g = load_golden(vid + "_seed0")
+        random.seed(int(g["seed"]))
+        np.random.seed(int(g["seed"]))
+        env = gym_lmaze.make("lmaze-" + vid)     # the constructor resets once, like the reference's
+        need_reset, n_reset, first = True, 0, None
+        for t in range(len(g["actions"])):
+            if need_reset:
+                o = env.reset()
+                assert obs_hash(o) == g["reset_hash"][n_reset]
+                assert (env.ball_x0, env.ball_y0) == tuple(g["ball_before"][t])
+                assert (env.goal_x, env.goal_y) == tuple(g["goal_before"][t])
+                n_reset += 1
+                need_reset = False
+            a = int(g["actions"][t])
+            o, r, d, info = env.step(a)
+            first = o if first is None else first
+            assert o is first and info == a and type(r) is float and type(d) is bool
+            assert r == g["reward"][t] and d == bool(g["done"][t]), (vid, t)
+            assert obs_hash(o) == g["obs_hash"][t], (vid, t)
+            need_reset = d
+        with pytest.raises(IndexError):
+            env.step(25)
+    assert gym_lmaze.make("lmaze-v2").observation_space.shape == (5, 35, 35)
+
+
+def test_dropin_v1_six_tuple():
+    import gym_lmaze
+    g = load_golden("v1_scripted_goal")
+    env = gym_lmaze.make("lmaze-v1")
+    assert env.observation_space.shape == (4, 35, 35) and env.action_space.n == 4
+    need_reset, n_reset = True, 0
+    for t in range(len(g["actions"])):
+        if g["reset_before"][t]:
+            o = env.reset()
+            assert obs_hash(o) == g["reset_hash"][n_reset]
+            n_reset += 1
+        if g["setgoal_before"][t]:
+            o = env.setFovealGoal(*[int(v) for v in g["setgoal_ij"][t]])
+            assert o.shape == (4, 35, 35)
+        out = env.step(int(g["actions"][t]))
+        assert len(out) == 6
+        o, r, fr, fd, d, info = out
+        assert (r, fr, fd, d) == (g["reward"][t], g["foveal_reward"][t], bool(g["foveal_done"][t]), bool(g["done"][t])), t
+        assert obs_hash(o) == g["obs_hash"][t], t
+        assert env.isEpisodeFinished() == d and env.fovealStepCount == g["foveal_step_count"][t]
+    assert (env.goal_x, env.goal_y) == tuple(g["goal"])

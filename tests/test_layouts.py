@@ -15,6 +15,11 @@ def test_tables_match_reference_layouts():
     assert (L.to_codes(L.V3_GRID_18) == load_golden("v3_g18_seed0")["layout"]).all()
     assert (L.to_codes(L.GRID_8_BORDERED) == load_golden("v0_g8_seed0")["layout"]).all()
     assert (L.to_codes(L.open_room(11, (5, 5))) == load_golden("v0_g11_open_seed0")["layout"]).all()
+    assert (L.to_codes(L.V1_GRID_14) == load_golden("v1_seed0")["layout"]).all()
+    five = load_golden("v2_seed0")["layouts"]
+    assert (five == load_golden("v4_seed0")["layouts"]).all()
+    for k, t in enumerate(L.FOVEAL_GRIDS_18):
+        assert (L.to_codes(t) == five[k]).all(), k
 
 
 def test_all_tables_valid():
@@ -45,7 +50,7 @@ def test_validate_rejects_open_border_and_bad_cells():
 
 def test_registry_ids_and_entry_points():
     import gym_lmaze
-    assert gym_lmaze.registered_ids() == ["lmaze-v0", "lmaze-v3"]
+    assert gym_lmaze.registered_ids() == ["lmaze-v0", "lmaze-v1", "lmaze-v2", "lmaze-v3", "lmaze-v4"]
     from gym_lmaze.envs import LmazeEnv, LmazeEnv_v3
     assert LmazeEnv.__name__ == "LmazeEnv" and LmazeEnv_v3.__name__ == "LmazeEnv_v3"
     with pytest.raises(KeyError):
