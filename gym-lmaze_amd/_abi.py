@@ -12,7 +12,7 @@ LIB_PATH = os.path.join(HERE, "liblmaze_hip.so")
 
 ABI_VERSION = 1
 VARIANT_V0, VARIANT_V3 = 0, 3
-VARIANT_V1, VARIANT_V2, VARIANT_V4 = 1, 2, 4
+VARIANT_V1, VARIANT_V2, VARIANT_V4, VARIANT_V5, VARIANT_V6 = 1, 2, 4, 5, 6
 FOVEA = 5
 LAYOUT_SHARED, LAYOUT_PER_ENV = 0, 1
 OBS_BALL, OBS_WALL, OBS_GOAL, OBS_FREE = 1, 2, 4, 8
@@ -23,7 +23,7 @@ MAX_GRID, MAX_CHANNELS = 64, 8
 SYMBOLS = ("lmaze_abi_version", "lmaze_strerror", "lmaze_device_info", "lmaze_step_v0", "lmaze_step_v3",
            "lmaze_step_v0_autoreset", "lmaze_step_v3_autoreset", "lmaze_observe", "lmaze_reset",
            "lmaze_render_expanded", "lmaze_foveal_step", "lmaze_foveal_reset", "lmaze_v1_set_foveal_goal",
-           "lmaze_expand_planes")
+           "lmaze_v5_planner_step", "lmaze_v6_safe_foveal_goal", "lmaze_expand_planes")
 
 
 class LmazeParams(C.Structure):
@@ -41,7 +41,8 @@ class LmazeFovealParams(C.Structure):
 
 
 FOVEAL_BUFFER_FIELDS = ("ball_xy", "goal_xy", "fgoal_xy", "layout_id", "step_count", "foveal_step_count",
-                        "reward", "foveal_reward", "done", "foveal_done", "visit", "obs")
+                        "reward", "foveal_reward", "done", "foveal_done", "visit", "obs",
+                        "ball1_xy", "fovea_xy", "last_xy", "foveal_goal", "obs_local")
 
 
 class LmazeFovealBuffers(C.Structure):
@@ -90,6 +91,10 @@ def _load():
     lib.lmaze_foveal_reset.argtypes = [FP, vp, vp, i32, u64, u64, i64, FB, i64, vp]
     lib.lmaze_v1_set_foveal_goal.restype = C.c_int
     lib.lmaze_v1_set_foveal_goal.argtypes = [FP, vp, vp, vp, FB, i64, vp]
+    lib.lmaze_v5_planner_step.restype = C.c_int
+    lib.lmaze_v5_planner_step.argtypes = [FP, vp, vp, vp, FB, i64, vp]
+    lib.lmaze_v6_safe_foveal_goal.restype = C.c_int
+    lib.lmaze_v6_safe_foveal_goal.argtypes = [FP, vp, u64, u64, i64, FB, vp, i64, vp]
     lib.lmaze_expand_planes.restype = C.c_int
     lib.lmaze_expand_planes.argtypes = [vp, i32, i32, i32, vp, i64, vp]
     if lib.lmaze_abi_version() != ABI_VERSION:

@@ -17,7 +17,7 @@ namespace lmaze {
 constexpr int FOV = LMAZE_FOVEA;
 constexpr int W25 = FOV * FOV;
 
-enum FovealMode { FM_STEP = 0, FM_RESET = 1, FM_SETGOAL = 2 };
+enum FovealMode { FM_STEP = 0, FM_RESET = 1, FM_SETGOAL = 2, FM_PLANNER = 3 };
 
 struct FovealArgs {
     LmazeFovealParams p;
@@ -39,7 +39,13 @@ struct EnvRec {           // what the render phase needs about one env
     int16_t action;       // v2/v4 action plane (-1: none); v1: 1 = local view, 0 = global view
     int32_t skip;         // env untouched by this call: neither state nor obs are written
     int32_t flat;         // v1 local view: flat index of the one-hot goal (numpy wrap applied), -1 none
+    int16_t b0x, b0y;     // v5/v6 local observation: ball, previous ball, fovea_1 (v5:364-365)
+    int16_t b1x, b1y;
+    int16_t f1x, f1y;
+    int16_t upd;          // v5/v6: localDone -> this call halves the visit map (v5:313-318)
+    int16_t pad;
 };
+static_assert(sizeof(EnvRec) == 40, "EnvRec layout");
 
 __device__ __forceinline__ float free_plane(uint8_t c) { return (c == 'B' || c == 'S' || c == 'X') ? 1.0f : 0.0f; }
 
@@ -77,8 +83,8 @@ __device__ __forceinline__ float obs_element(const EnvRec& r, const uint8_t* lay
                                      : ((in && c == 'X') ? 1.0f : 0.0f);             // global goal, v1:74
         return in ? free_plane(c) : 0.0f;                                        // free, v1:78
     }
-    constexpr int PER = VARIANT == LMAZE_VARIANT_V4 ? 3 : 2;
-    if (ch == PER) return (r.action == i * FOV + j) ? 1.0f : 0.0f;               // action plane, v2:135-136
+    constexpr int PER = VARIANT == LMAZE_VARIANT_V2 ? 2 : 3;
+    if (ch == PER) return (r.action == i * FOV + j) ? 1.0f : 0.0f;               // action plane v2:135-136 / fovealGoal v5:166-169
     const bool prev = ch > PER;
     const int plane = prev ? ch - PER - 1 : ch;
     const int x = (prev ? r.px : r.cx) - 2 + i, y = (prev ? r.py : r.cy) - 2 + j;
@@ -88,9 +94,30 @@ __device__ __forceinline__ float obs_element(const EnvRec& r, const uint8_t* lay
     return in ? visit_tile[x * G + y] : 0.0f;                                         // v4 visit map (live view)
 }
 
+// numpy index semantics on an axis of 5: -5..-1 wrap, anything else outside 0..4 raises (-> -1)
+__device__ __forceinline__ int wrap5(int i) {
+    if (i >= 0 && i < FOV) return i;
+    if (i < 0 && i >= -FOV) return i + FOV;
+    return -1;
+}
+
+// v5 buildLocalObservation (v5:356-380): free window at fovea_0, ball and previous ball relative to
+// fovea_1, fovealGoal plane
+__device__ __forceinline__ float loc_element(const EnvRec& r, const uint8_t* lays, int G, int ch, int i, int j) {
+    if (ch == 0) {
+        const int x = r.cx - 2 + i, y = r.cy - 2 + j;
+        const bool in = x >= 0 && y >= 0 && x < G && y < G;
+        return in ? free_plane(lays[r.lid * G * G + x * G + y]) : 0.0f;
+    }
+    if (ch == 3) return (r.action == i * FOV + j) ? 1.0f : 0.0f;
+    const int bi = wrap5((ch == 1 ? r.b0x : r.b1x) - r.f1x + 2), bj = wrap5((ch == 1 ? r.b0y : r.b1y) - r.f1y + 2);
+    return (bi == i && bj == j) ? 1.0f : 0.0f;
+}
+
 template <int VARIANT, int MODE, int EPB>
 __global__ __launch_bounds__(LMAZE_BLOCK) void foveal_kernel(const FovealArgs a) {
-    constexpr bool V1 = VARIANT == LMAZE_VARIANT_V1, V4 = VARIANT == LMAZE_VARIANT_V4;
+    constexpr bool V1 = VARIANT == LMAZE_VARIANT_V1, V5 = VARIANT == LMAZE_VARIANT_V5;
+    constexpr bool V4 = VARIANT == LMAZE_VARIANT_V4 || V5;   // "has a visit map"
     constexpr int C = V1 ? 4 : (V4 ? 7 : 5);
     constexpr int PERENV = C * W25;  // floats of observation per env
     const int G = a.p.grid, CELLS = G * G, L = V1 ? 1 : a.p.n_layouts;
@@ -113,6 +140,7 @@ __global__ __launch_bounds__(LMAZE_BLOCK) void foveal_kernel(const FovealArgs a)
         const int64_t e = blockbase + le;
         EnvRec r;
         r.skip = 0; r.flat = -1; r.action = -1; r.lid = 0; r.gx = r.gy = -9;
+        r.b0x = r.b0y = r.b1x = r.b1y = r.f1x = r.f1y = 0; r.upd = 0; r.pad = 0;
         int bx = a.b.ball_xy[2 * e], by = a.b.ball_xy[2 * e + 1];
         r.px = (int16_t)bx; r.py = (int16_t)by;
         if (MODE != FM_STEP && a.mask && !a.mask[e]) r.skip = 1;
@@ -170,6 +198,110 @@ __global__ __launch_bounds__(LMAZE_BLOCK) void foveal_kernel(const FovealArgs a)
             int flat = fgx * G + fgy;                                  // v1:244-245, numpy negative-index wrap
             if (flat < 0) flat += CELLS;
             r.flat = (flat >= 0 && flat < CELLS) ? flat : -1;
+        } else if (V5) {
+            int lid = clampi(a.b.layout_id[e], 0, L - 1);
+            int gx = a.b.goal_xy[2 * e], gy = a.b.goal_xy[2 * e + 1];
+            int fg = a.b.foveal_goal[e];
+            int f0x = a.b.fovea_xy[4 * e], f0y = a.b.fovea_xy[4 * e + 1];
+            int f1x = a.b.fovea_xy[4 * e + 2], f1y = a.b.fovea_xy[4 * e + 3];
+            int b1x = a.b.ball1_xy[2 * e], b1y = a.b.ball1_xy[2 * e + 1];
+            int lx = a.b.last_xy[2 * e], ly = a.b.last_xy[2 * e + 1];
+            if (MODE == FM_STEP) {                                     // v5:187-292
+                const uint8_t* lay = lays + lid * CELLS;
+                const int act = a.action[e];
+                const int fgx = a.b.fgoal_xy[2 * e], fgy = a.b.fgoal_xy[2 * e + 1];
+                const int fsc = a.b.foveal_step_count[e];
+                bool ld = a.b.foveal_done[e] != 0, gd = a.b.done[e] != 0;   // both persist across step() calls
+                b1x = bx; b1y = by;                                    // v5:193-194
+                float lr = -0.0f, gr;                                  // v5:196
+                const int sc = a.b.step_count[e] + 1;                  // v5:197
+                const int dx = (act == 0) - (act == 1), dy = (act == 2) - (act == 3);   // v5:205-217
+                const int nx = bx + dx, ny = by + dy;
+                const bool nin = nx >= 0 && ny >= 0 && nx < G && ny < G;
+                const uint8_t c = nin ? lay[nx * G + ny] : (uint8_t)'W';
+                if (c == 'W') {                                        // v5:232-233
+                    lr = a.p.reward_wall;
+                } else if (nx == fgx && ny == fgy) {                   // v5:235-239
+                    lr = a.p.reward_goal; bx = nx; by = ny; ld = true;
+                } else if (c == 'B' || c == 'S' || c == 'X') {         // v5:241-248
+                    if (nx < f1x - 3 || nx > f1x + 2 || ny < f1y - 3 || ny > f1y + 2) ld = true;
+                    lr = a.p.reward_move; bx = nx; by = ny;
+                }
+                if (nx == gx && ny == gy) { gr = a.p.reward_goal; gd = true; }   // v5:254-262
+                else if (nx == fgx && ny == fgy) gr = a.p.reward_move;
+                else gr = a.p.reward_wall;
+                f0x = bx; f0y = by;                                    // v5:264-265
+                if (sc >= a.p.step_limit) ld = true;                   // v5:267
+                if (fsc >= a.p.foveal_step_limit) { gd = true; ld = true; }   // v5:269-271
+                if (fsc == 0) { lx = f0x; ly = f0y; }                  // v5:322-323
+                r.px = (int16_t)lx; r.py = (int16_t)ly;                // window the foveal obs shows as "previous"
+                r.upd = ld ? 1 : 0;                                    // v5:313-318
+                if (ld) { lx = f0x; ly = f0y; }                        // v5:344-346 (after the render)
+                a.b.ball_xy[2 * e] = bx; a.b.ball_xy[2 * e + 1] = by;
+                a.b.ball1_xy[2 * e] = b1x; a.b.ball1_xy[2 * e + 1] = b1y;
+                a.b.fovea_xy[4 * e] = f0x; a.b.fovea_xy[4 * e + 1] = f0y;
+                a.b.last_xy[2 * e] = lx; a.b.last_xy[2 * e + 1] = ly;
+                a.b.step_count[e] = sc;
+                a.b.reward[e] = gr; a.b.foveal_reward[e] = lr;
+                a.b.done[e] = gd ? 1 : 0; a.b.foveal_done[e] = ld ? 1 : 0;
+            } else if (MODE == FM_PLANNER && !r.skip) {                // v5:158-182
+                const int g = a.action[e];
+                if (g < 0 || g >= W25) {
+                    r.skip = 1;                                        // the reference raises half-way (v5:169)
+                } else {
+                    fg = g;
+                    a.b.step_count[e] = 0;                             // v5:160
+                    a.b.reward[e] = -0.0f;                             // v5:161
+                    a.b.foveal_done[e] = 0;                            // v5:162
+                    a.b.foveal_goal[e] = g;
+                    a.b.fgoal_xy[2 * e] = bx + g / FOV - 2;            // v5:172-173
+                    a.b.fgoal_xy[2 * e + 1] = by + g % FOV - 2;
+                    const int fsc = a.b.foveal_step_count[e];
+                    if (fsc > 0) {                                     // v5:175-177
+                        f1x = f0x; f1y = f0y;
+                        a.b.fovea_xy[4 * e + 2] = f1x; a.b.fovea_xy[4 * e + 3] = f1y;
+                    }
+                    a.b.foveal_step_count[e] = fsc + 1;                // v5:179
+                }
+            } else if (MODE == FM_RESET && !r.skip) {                  // v5:104-150
+                if (a.place) {
+                    const uint4 d = env_draw(a.seed, a.epoch, a.env_base + e);
+                    lid = (int)__umulhi(d.z, (uint32_t)L);             // v5:105 setGrid first
+                    a.b.layout_id[e] = lid;
+                    const uint8_t* lay = lays + lid * CELLS;
+                    const int cg = count_or_kth(lay, G, 0, -1, -1);
+                    int goal_cell = -1;
+                    if (cg > 0) {
+                        goal_cell = count_or_kth(lay, G, 0, -1, (int)__umulhi(d.x, (uint32_t)cg));
+                        gx = goal_cell / G; gy = goal_cell % G;
+                        a.b.goal_xy[2 * e] = gx; a.b.goal_xy[2 * e + 1] = gy;
+                    }
+                    const int cb = count_or_kth(lay, G, 1, goal_cell, -1);
+                    if (cb > 0) {
+                        const int cell = count_or_kth(lay, G, 1, goal_cell, (int)__umulhi(d.y, (uint32_t)cb));
+                        bx = cell / G; by = cell % G;
+                        a.b.ball_xy[2 * e] = bx; a.b.ball_xy[2 * e + 1] = by;
+                    }
+                }
+                a.b.foveal_reward[e] = -0.0f; a.b.reward[e] = -0.0f;   // v5:107-108
+                a.b.foveal_step_count[e] = 0; a.b.step_count[e] = 0;   // v5:109-110
+                a.b.done[e] = 0; a.b.foveal_done[e] = 0;               // v5:111-112
+                fg = 12;                                               // v5:127-128
+                a.b.foveal_goal[e] = fg;
+                f0x = f1x = b1x = lx = bx; f0y = f1y = b1y = ly = by;  // v5:136-143
+                a.b.fovea_xy[4 * e] = bx; a.b.fovea_xy[4 * e + 1] = by;
+                a.b.fovea_xy[4 * e + 2] = bx; a.b.fovea_xy[4 * e + 3] = by;
+                a.b.fgoal_xy[2 * e] = bx; a.b.fgoal_xy[2 * e + 1] = by;
+                a.b.ball1_xy[2 * e] = bx; a.b.ball1_xy[2 * e + 1] = by;
+                a.b.last_xy[2 * e] = bx; a.b.last_xy[2 * e + 1] = by;
+                r.px = (int16_t)bx; r.py = (int16_t)by;
+            }
+            r.lid = (int16_t)lid;
+            r.gx = (int16_t)gx; r.gy = (int16_t)gy;
+            r.action = (int16_t)fg;
+            r.b0x = (int16_t)bx; r.b0y = (int16_t)by; r.b1x = (int16_t)b1x; r.b1y = (int16_t)b1y;
+            r.f1x = (int16_t)f1x; r.f1y = (int16_t)f1y;
+            bx = f0x; by = f0y;                                        // the window centre is fovea_0
         } else {
             int lid = a.b.layout_id[e];
             int gx = a.b.goal_xy[2 * e], gy = a.b.goal_xy[2 * e + 1];
@@ -241,7 +373,7 @@ __global__ __launch_bounds__(LMAZE_BLOCK) void foveal_kernel(const FovealArgs a)
     const bool some_skipped = any_skip != 0;
 
     // ---------------- phase 2 (v4): stream the visit maps, v4:116-119 / v4:211-214 ----------------
-    if (V4) {
+    if (V4 && !(V5 && MODE == FM_PLANNER)) {
         float* vis = a.b.visit + (size_t)blockbase * CELLS;
         const int total = nb * CELLS;
         if ((CELLS & 3) == 0) {  // a 16-byte access never straddles two envs
@@ -252,7 +384,9 @@ __global__ __launch_bounds__(LMAZE_BLOCK) void foveal_kernel(const FovealArgs a)
                 const int c0 = f0 - le * CELLS;
                 float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
                 if (r.skip || MODE == FM_STEP) v = reinterpret_cast<const float4*>(vis)[q];
-                if (!r.skip) {
+                if (V5 && !r.skip && MODE == FM_RESET) {
+                    reinterpret_cast<float4*>(vis)[q] = v;             // v5:130: zeroed, no window added at reset
+                } else if (!r.skip && (!V5 || r.upd)) {
                     float* pv = reinterpret_cast<float*>(&v);
 #pragma unroll
                     for (int k = 0; k < 4; ++k) {
@@ -270,7 +404,9 @@ __global__ __launch_bounds__(LMAZE_BLOCK) void foveal_kernel(const FovealArgs a)
                 const EnvRec r = rec[le];
                 const int c = f - le * CELLS;
                 float v = (r.skip || MODE == FM_STEP) ? vis[f] : 0.0f;
-                if (!r.skip) {
+                if (V5 && !r.skip && MODE == FM_RESET) {
+                    vis[f] = v;
+                } else if (!r.skip && (!V5 || r.upd)) {
                     const int x = c / G, y = c - x * G;
                     const float w = (x >= r.cx - 2 && x <= r.cx + 2 && y >= r.cy - 2 && y <= r.cy + 2) ? 1.0f : 0.0f;
                     v = (v + w) * 0.5f;
@@ -284,7 +420,7 @@ __global__ __launch_bounds__(LMAZE_BLOCK) void foveal_kernel(const FovealArgs a)
 
     // ---------------- phase 3: render float[nb*C*25], contiguous, 16-byte stores ----------------
     float* obs = a.b.obs + (size_t)blockbase * PERENV;
-    const int R = nb * PERENV;
+    const int R = (V5 && MODE == FM_PLANNER) ? 0 : nb * PERENV;   // plannerStep returns only the local observation
     const int nq = some_skipped ? 0 : (R >> 2);
     for (int q = tid; q < nq; q += LMAZE_BLOCK) {
         int f = q << 2;
@@ -307,6 +443,53 @@ __global__ __launch_bounds__(LMAZE_BLOCK) void foveal_kernel(const FovealArgs a)
         const int ch = rem / W25, cell = rem - ch * W25;
         obs[f] = obs_element<VARIANT>(rec[le], lays, vtile + le * CELLS, G, ch, cell / FOV, cell % FOV);
     }
+
+    // ---------------- phase 3b (v5/v6): the local observation float[nb*4*25], v5:356-380 ----------------
+    if (V5 && MODE != FM_RESET) {
+        constexpr int PERLOC = 4 * W25;
+        float* loc = a.b.obs_local + (size_t)blockbase * PERLOC;
+        const int RL = nb * PERLOC;                      // 100 floats per env: a store never straddles two envs
+        for (int q = tid; q < (RL >> 2); q += LMAZE_BLOCK) {
+            const int f = q << 2;
+            const int le = f / PERLOC;
+            if (rec[le].skip) continue;
+            const int rem = f - le * PERLOC;
+            float v[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int ch = (rem + k) / W25, cell = (rem + k) - ch * W25;
+                v[k] = loc_element(rec[le], lays, G, ch, cell / FOV, cell % FOV);
+            }
+            reinterpret_cast<float4*>(loc)[q] = make_float4(v[0], v[1], v[2], v[3]);
+        }
+    }
+}
+
+// v6 safeFovealGoal (v6:505-523): one lane per env
+__global__ __launch_bounds__(LMAZE_BLOCK) void safe_goal_kernel(const FovealArgs a, int32_t* out_goal) {
+    const int64_t e = (int64_t)blockIdx.x * LMAZE_BLOCK + threadIdx.x;
+    if (e >= a.n) return;
+    const int G = a.p.grid;
+    const uint8_t* lay = a.layouts + (size_t)clampi(a.b.layout_id[e], 0, a.p.n_layouts - 1) * G * G;
+    const int bx = a.b.ball_xy[2 * e], by = a.b.ball_xy[2 * e + 1];
+    const uint4 d = env_draw(a.seed, a.epoch, a.env_base + e);
+    unsigned ok = 0;
+    for (int c = 0; c < W25; ++c) {
+        const int x = bx - 2 + c / FOV, y = by - 2 + c % FOV;
+        const bool in = x >= 0 && y >= 0 && x < G && y < G;
+        if (in && lay[x * G + y] != 'W') ok |= 1u << c;
+    }
+    int pick = 12;
+    const int cnt = __popc(ok);
+    if (cnt > 0) {
+        int k = (int)__umulhi(d.x, (uint32_t)cnt);
+        for (int c = 0; c < W25; ++c)
+            if (ok & (1u << c)) {
+                if (k == 0) { pick = c; break; }
+                --k;
+            }
+    }
+    out_goal[e] = pick;
 }
 
 // ------------------------------------------------------------------------------------
@@ -375,7 +558,7 @@ static hipError_t launch_foveal_one(const FovealArgs& a, hipStream_t s) {
     const int cells = a.p.grid * a.p.grid;
     const int L = VARIANT == LMAZE_VARIANT_V1 ? 1 : a.p.n_layouts;
     size_t lds = sizeof(EnvRec) * EPB + (size_t)((L * cells + 15) & ~15);
-    if (VARIANT == LMAZE_VARIANT_V4) lds += (size_t)EPB * cells * 4;
+    if (VARIANT == LMAZE_VARIANT_V4 || VARIANT == LMAZE_VARIANT_V5) lds += (size_t)EPB * cells * 4;
     const int64_t blocks = (a.n + EPB - 1) / EPB;
     hipLaunchKernelGGL((foveal_kernel<VARIANT, MODE, EPB>), dim3((unsigned)blocks), dim3(LMAZE_BLOCK), lds, s, a);
     return hipGetLastError();
@@ -387,6 +570,10 @@ static hipError_t launch_foveal_mode(const FovealArgs& a, hipStream_t s) {
     switch (a.p.variant) {
         case LMAZE_VARIANT_V1: return launch_foveal_one<LMAZE_VARIANT_V1, MODE, 256>(a, s);
         case LMAZE_VARIANT_V2: return launch_foveal_one<LMAZE_VARIANT_V2, MODE, 256>(a, s);
+        case LMAZE_VARIANT_V5:
+        case LMAZE_VARIANT_V6:
+            if (a.p.grid * a.p.grid * 4 * 32 <= 96 * 1024) return launch_foveal_one<LMAZE_VARIANT_V5, MODE, 32>(a, s);
+            return launch_foveal_one<LMAZE_VARIANT_V5, MODE, 8>(a, s);
         default:
             // v4 tiles the workgroup's visit maps in LDS: 32 envs of 18x18 floats = 41 KiB
             if (a.p.grid * a.p.grid * 4 * 32 <= 96 * 1024) return launch_foveal_one<LMAZE_VARIANT_V4, MODE, 32>(a, s);
@@ -396,11 +583,18 @@ static hipError_t launch_foveal_mode(const FovealArgs& a, hipStream_t s) {
 
 static int check_foveal(const LmazeFovealParams* p, const uint8_t* layouts, const LmazeFovealBuffers* b, int64_t n) {
     if (!p || !layouts || !b) return LMAZE_E_NULL;
-    if (p->variant != LMAZE_VARIANT_V1 && p->variant != LMAZE_VARIANT_V2 && p->variant != LMAZE_VARIANT_V4)
+    const bool v56 = p->variant == LMAZE_VARIANT_V5 || p->variant == LMAZE_VARIANT_V6;
+    if (p->variant != LMAZE_VARIANT_V1 && p->variant != LMAZE_VARIANT_V2 && p->variant != LMAZE_VARIANT_V4 && !v56)
         return LMAZE_E_VARIANT;
     if (p->grid < FOV || p->grid > LMAZE_MAX_GRID) return LMAZE_E_GRID;
     if (p->n_layouts < 1 || p->n_layouts > LMAZE_MAX_LAYOUTS) return LMAZE_E_LAYOUT;
     if (n < 0 || n > ((int64_t)1 << 40)) return LMAZE_E_COUNT;
+    if (v56) {
+        if (!b->fgoal_xy || !b->foveal_step_count || !b->foveal_reward || !b->foveal_done || !b->visit || !b->ball1_xy ||
+            !b->fovea_xy || !b->last_xy || !b->foveal_goal || !b->obs_local)
+            return LMAZE_E_NULL;
+        if ((uintptr_t)b->obs_local & 15) return LMAZE_E_ALIGN;
+    }
     if (!b->ball_xy || !b->step_count || !b->reward || !b->done || !b->obs) return LMAZE_E_NULL;
     if (p->variant == LMAZE_VARIANT_V1 && (!b->fgoal_xy || !b->foveal_step_count || !b->foveal_reward || !b->foveal_done))
         return LMAZE_E_NULL;
@@ -466,6 +660,35 @@ int lmaze_v1_set_foveal_goal(const LmazeFovealParams* params, const uint8_t* lay
     a.mask = mask;
     if (n == 0) return 0;
     return (int)launch_foveal_one<LMAZE_VARIANT_V1, FM_SETGOAL, 256>(a, (hipStream_t)stream);
+}
+
+int lmaze_v5_planner_step(const LmazeFovealParams* params, const uint8_t* layouts, const int32_t* goal,
+                          const uint8_t* mask, const LmazeFovealBuffers* bufs, int64_t n, void* stream) {
+    int rc = check_foveal(params, layouts, bufs, n);
+    if (rc) return rc;
+    if (params->variant != LMAZE_VARIANT_V5 && params->variant != LMAZE_VARIANT_V6) return LMAZE_E_VARIANT;
+    if (!goal) return LMAZE_E_NULL;
+    FovealArgs a = make_foveal_args(params, layouts, bufs, n);
+    a.action = goal;
+    a.mask = mask;
+    return (int)launch_foveal_mode<FM_PLANNER>(a, (hipStream_t)stream);
+}
+
+int lmaze_v6_safe_foveal_goal(const LmazeFovealParams* params, const uint8_t* layouts, uint64_t seed, uint64_t epoch,
+                              int64_t env_base, const LmazeFovealBuffers* bufs, int32_t* out_goal, int64_t n,
+                              void* stream) {
+    int rc = check_foveal(params, layouts, bufs, n);
+    if (rc) return rc;
+    if (params->variant != LMAZE_VARIANT_V5 && params->variant != LMAZE_VARIANT_V6) return LMAZE_E_VARIANT;
+    if (!out_goal) return LMAZE_E_NULL;
+    if (n == 0) return 0;
+    FovealArgs a = make_foveal_args(params, layouts, bufs, n);
+    a.seed = seed;
+    a.epoch = epoch;
+    a.env_base = env_base;
+    hipLaunchKernelGGL(safe_goal_kernel, dim3((unsigned)((n + LMAZE_BLOCK - 1) / LMAZE_BLOCK)), dim3(LMAZE_BLOCK), 0,
+                       (hipStream_t)stream, a, out_goal);
+    return (int)hipGetLastError();
 }
 
 int lmaze_expand_planes(const float* planes, int32_t channels, int32_t g, int32_t expansion, float* out, int64_t n,

@@ -24,6 +24,11 @@ FOVEAL_VARIANTS = {
     # lmaze_env_v4.py:23-48
     "v4": dict(id=_abi.VARIANT_V4, layouts=L.FOVEAL_GRIDS_18, channels=7, expansion=7, step_limit=50,
                foveal_step_limit=0, rewards=(-1.0, -0.01, 100.0), n_actions=25),
+    # lmaze_env_v5.py:21-49: local step limit 10 (>=), foveal step limit 50 (>=); 4 local actions, 25 planner goals
+    "v5": dict(id=_abi.VARIANT_V5, layouts=L.FOVEAL_GRIDS_18, channels=7, expansion=7, step_limit=10,
+               foveal_step_limit=50, rewards=(-1.0, -0.01, 100.0), n_actions=4),
+    "v6": dict(id=_abi.VARIANT_V6, layouts=L.FOVEAL_GRIDS_18, channels=7, expansion=7, step_limit=10,
+               foveal_step_limit=50, rewards=(-1.0, -0.01, 100.0), n_actions=4),
 }
 
 
@@ -61,7 +66,8 @@ class LmazeFovealVecEnv(object):
 
         sizes = [("ball_xy", 8 * N), ("goal_xy", 8 * N), ("fgoal_xy", 8 * N), ("layout_id", 4 * N),
                  ("step_count", 4 * N), ("foveal_step_count", 4 * N), ("reward", 4 * N), ("foveal_reward", 4 * N),
-                 ("done", N), ("foveal_done", N)]
+                 ("done", N), ("foveal_done", N), ("ball1_xy", 8 * N), ("fovea_xy", 16 * N), ("last_xy", 8 * N),
+                 ("foveal_goal", 4 * N)]
         offs, total = {}, 0
         for name, sz in sizes:
             offs[name] = total
@@ -83,7 +89,16 @@ class LmazeFovealVecEnv(object):
         self._fdone_u8 = view("foveal_done", N, torch.uint8, (N,))
         self.done = self._done_u8.view(torch.bool)
         self.foveal_done = self._fdone_u8.view(torch.bool)
-        self.visit = torch.zeros((N, G, G), dtype=torch.float32, device=self.device) if variant == "v4" else None
+        self.ball1_xy = view("ball1_xy", 8 * N, torch.int32, (N, 2))
+        self.fovea_xy = view("fovea_xy", 16 * N, torch.int32, (N, 4))
+        self.last_xy = view("last_xy", 8 * N, torch.int32, (N, 2))
+        self.foveal_goal = view("foveal_goal", 4 * N, torch.int32, (N,))
+        self._two_level = variant in ("v5", "v6")
+        has_visit = variant in ("v4", "v5", "v6")
+        self.visit = torch.zeros((N, G, G), dtype=torch.float32, device=self.device) if has_visit else None
+        self.obs_local = (torch.zeros((N, 4, _abi.FOVEA, _abi.FOVEA), dtype=torch.float32, device=self.device)
+                          if self._two_level else None)
+        self._expanded_local = None
         self.obs = torch.zeros((N, self.channels, _abi.FOVEA, _abi.FOVEA), dtype=torch.float32, device=self.device)
         self._expanded = None
         self._names = sizes
@@ -96,7 +111,9 @@ class LmazeFovealVecEnv(object):
             self.ball_xy.data_ptr(), self.goal_xy.data_ptr(), self.fgoal_xy.data_ptr(), self.layout_id.data_ptr(),
             self.step_count.data_ptr(), self.foveal_step_count.data_ptr(), self.reward.data_ptr(),
             self.foveal_reward.data_ptr(), self._done_u8.data_ptr(), self._fdone_u8.data_ptr(),
-            self.visit.data_ptr() if self.visit is not None else None, self.obs.data_ptr())
+            self.visit.data_ptr() if self.visit is not None else None, self.obs.data_ptr(),
+            self.ball1_xy.data_ptr(), self.fovea_xy.data_ptr(), self.last_xy.data_ptr(), self.foveal_goal.data_ptr(),
+            self.obs_local.data_ptr() if self.obs_local is not None else None)
         self._pb = C.byref(self.bufs)
         self._p_layouts = self.layouts.data_ptr()
         if variant == "v1":
@@ -167,6 +184,38 @@ class LmazeFovealVecEnv(object):
         _abi.check("lmaze_v1_set_foveal_goal", rc)
         return self.obs
 
+    def planner_step(self, goal, mask=None):
+        """v5/v6 plannerStep(goal) (lmaze_env_v5.py:158-182); goal int[N] in 0..24.  Returns obs_local."""
+        t = self._as_i32(goal, self.num_envs)
+        m, m_ptr = self._mask_ptr(mask)
+        with self._guard():
+            rc = _abi.lib.lmaze_v5_planner_step(self._pp, self._p_layouts, t.data_ptr(), m_ptr, self._pb,
+                                                self.num_envs, self._stream())
+        _abi.check("lmaze_v5_planner_step", rc)
+        return self.obs_local
+
+    def safe_foveal_goal(self):
+        """v6 safeFovealGoal() (lmaze_env_v6.py:505-523): int32[N] window cell that is not a wall."""
+        out = torch.empty(self.num_envs, dtype=torch.int32, device=self.device)
+        with self._guard():
+            rc = _abi.lib.lmaze_v6_safe_foveal_goal(self._pp, self._p_layouts, self.seed & (2 ** 64 - 1), self._epoch,
+                                                    self.env_base, self._pb, out.data_ptr(), self.num_envs,
+                                                    self._stream())
+        _abi.check("lmaze_v6_safe_foveal_goal", rc)
+        self._epoch += 1
+        return out
+
+    def expanded_local(self):
+        """(4,35,35) reference layout of obs_local (lmaze_env_v5.py:373-379)."""
+        N, E = self.num_envs, self.expansion
+        if self._expanded_local is None:
+            self._expanded_local = torch.empty((N, 4, 5 * E, 5 * E), dtype=torch.float32, device=self.device)
+        with self._guard():
+            rc = _abi.lib.lmaze_expand_planes(self.obs_local.data_ptr(), 4, _abi.FOVEA, E,
+                                              self._expanded_local.data_ptr(), N, self._stream())
+        _abi.check("lmaze_expand_planes", rc)
+        return self._expanded_local
+
     def set_state(self, **kw):
         for name, src in kw.items():
             dst = {"done": self._done_u8, "foveal_done": self._fdone_u8}.get(name, getattr(self, name))
@@ -194,7 +243,9 @@ class LmazeFovealVecEnv(object):
                             ("step_count", self.step_count, np.int32),
                             ("foveal_step_count", self.foveal_step_count, np.int32),
                             ("reward", self.reward, np.float32), ("foveal_reward", self.foveal_reward, np.float32),
-                            ("done", self._done_u8, np.uint8), ("foveal_done", self._fdone_u8, np.uint8)):
+                            ("done", self._done_u8, np.uint8), ("foveal_done", self._fdone_u8, np.uint8),
+                            ("ball1_xy", self.ball1_xy, np.int32), ("fovea_xy", self.fovea_xy, np.int32),
+                            ("last_xy", self.last_xy, np.int32), ("foveal_goal", self.foveal_goal, np.int32)):
             off = t.data_ptr() - base
             out[name] = h[off:off + t.numel() * t.element_size()].view(dt).reshape(tuple(t.shape))
         return out

@@ -318,3 +318,118 @@ class LmazeEnv_v4(_TeleportBase):
         out[1, self.goal_x, self.goal_y] = 1.0
         out[2] = self._core.visit[0].cpu().numpy()
         return out
+
+
+# ----------------------------------------------------------------------------------------
+class LmazeEnv_v5(_TeleportBase):
+    """lmaze-v5: two-level planner / local env, plannerStep() + step(), 8-tuple return --
+    lmaze_env_v5.py:17-712.  Declares no spaces upstream (v5:41-43)."""
+    _variant = "v5"
+
+    def __init__(self, num_envs=1, device=None, obs_mode=None, seed=None):
+        self.state_type = "twoState-threeLayers"             # v5:23
+        self._common_init(3, num_envs, device, obs_mode, seed)
+        self.step_limit = 10                                 # v5:45-46
+        self.foveal_step_limit = 50
+        self.reset()                                         # v5:80
+
+    # reference attribute names (v5:62-78)
+    f_goal_x0 = property(lambda s: int(s._h("fgoal_xy")[0]))
+    f_goal_y0 = property(lambda s: int(s._h("fgoal_xy")[1]))
+    ball_x1 = property(lambda s: int(s._h("ball1_xy")[0]))
+    ball_y1 = property(lambda s: int(s._h("ball1_xy")[1]))
+    fovea_x0 = property(lambda s: int(s._h("fovea_xy")[0]))
+    fovea_y0 = property(lambda s: int(s._h("fovea_xy")[1]))
+    fovea_x1 = property(lambda s: int(s._h("fovea_xy")[2]))
+    fovea_y1 = property(lambda s: int(s._h("fovea_xy")[3]))
+    fovealStepCount = property(lambda s: int(s._h("foveal_step_count")) if s._single else s._core.foveal_step_count,
+                               lambda s, v: None)
+    globalReward = property(lambda s: s._reward_py(s._h("reward")) if s._single else s._core.reward)
+    originalReward = property(lambda s: s._reward_py(s._h("foveal_reward")) if s._single else s._core.foveal_reward)
+    globalDone = property(lambda s: bool(s._h("done")) if s._single else s._core.done)
+    localDone = property(lambda s: bool(s._h("foveal_done")) if s._single else s._core.foveal_done, lambda s, v: None)
+
+    @property
+    def fovealGoal(self):
+        """float32 (1,5,5) one-hot plane (v5:166-169)."""
+        if self._single:
+            p = np.zeros((1, 5, 5), np.float32)
+            p.reshape(-1)[int(self._h("foveal_goal"))] = 1.0
+            return p
+        return self._core.obs_local[:, 3:4]
+
+    def _fov(self):
+        if self.obs_mode == "compact":
+            return self._core.obs
+        return self._core.expanded()[0].cpu().numpy() if self._single else self._core.expanded()   # fresh array, v5:308
+
+    def _loc(self):
+        if self.obs_mode == "compact":
+            return self._core.obs_local
+        return self._core.expanded_local()[0].cpu().numpy() if self._single else self._core.expanded_local()
+
+    def reset(self, mask=None):
+        if self._single:
+            self.setGrid()                                   # v5:105, then goal, ball (v5:114-115)
+            self.setGoal()
+            self.setBall()
+            self._upload_and_reset()
+        else:
+            self._core.reset(mask=mask)
+            self._host = None
+        return self._fov()
+
+    def plannerStep(self, goal):                             # v5:158-182
+        if self._single:
+            g = int(goal)
+            if not 0 <= g < 25:
+                raise IndexError("index %d is out of bounds for the 5x5 fovealGoal plane (lmaze_env_v5.py:169)" % g)
+            self._core.planner_step(np.array([g], np.int32))
+        else:
+            self._core.planner_step(goal)
+        self._host = None
+        return self._loc()
+
+    def step(self, goal):                                    # v5:187-292
+        core = self._core
+        if self._single:
+            a = int(goal)
+            core.step(np.array([a if -2 ** 31 <= a < 2 ** 31 else -1], np.int32))
+            h = self._sync()
+            # the reference's buildLocalObservation indexes a 5x5 frame with ball - fovea_1 + 2 (v5:364-365)
+            for b in (h["ball_xy"][0], h["ball1_xy"][0]):
+                for k in (0, 1):
+                    idx = int(b[k]) - int(h["fovea_xy"][0][2 + k]) + 2
+                    if not -5 <= idx < 5:
+                        raise IndexError("index %d is out of bounds for axis with size 5 (lmaze_env_v5.py:364-365)" % idx)
+            return (self._fov(), self._loc(), self._reward_py(h["reward"][0]), self._reward_py(h["foveal_reward"][0]),
+                    bool(h["done"][0]), bool(h["foveal_done"][0]), self.fovealGoal, a)
+        core.step(goal)
+        self._host = None
+        return (self._fov(), self._loc(), core.reward, core.foveal_reward, core.done, core.foveal_done,
+                self.fovealGoal, goal)
+
+    def buildFovealObservation(self):
+        return self._fov()
+
+    def buildLocalObservation(self):
+        return self._loc()
+
+    def safeFovealGoal(self):                                # v5:501-502: a stub upstream
+        print("return a safe foveal goal for training local agent ")
+
+
+class LmazeEnv_v6(LmazeEnv_v5):
+    """lmaze-v6: v5 + safeFovealGoal() (lmaze_env_v6.py:505-523)."""
+    _variant = "v6"
+
+    def safeFovealGoal(self):
+        if not self._single:
+            return self._core.safe_foveal_goal()
+        g = self.grid
+        bx, by = self.ball_x0, self.ball_y0
+        small = g[bx - 2:bx + 3, by - 2:by + 3]              # v6:510, same np.random draws as the reference
+        a = np.random.randint(0, 25)
+        while small[int(a / 5)][a % 5] == 'W':
+            a = np.random.randint(0, 25)
+        return a

@@ -25,6 +25,8 @@ _ENTRY_POINTS = {
     "lmaze-v2": "gym_lmaze.envs:LmazeEnv_v2",
     "lmaze-v3": "gym_lmaze.envs:LmazeEnv_v3",
     "lmaze-v4": "gym_lmaze.envs:LmazeEnv_v4",
+    "lmaze-v5": "gym_lmaze.envs:LmazeEnv_v5",
+    "lmaze-v6": "gym_lmaze.envs:LmazeEnv_v6",
 }
 for _id, _ep in _ENTRY_POINTS.items():
     _impl.register(_id, _ep)

@@ -7,3 +7,5 @@ LmazeEnv_v3 = _impl.LmazeEnv_v3
 LmazeEnv_v1 = _impl.LmazeEnv_v1
 LmazeEnv_v2 = _impl.LmazeEnv_v2
 LmazeEnv_v4 = _impl.LmazeEnv_v4
+LmazeEnv_v5 = _impl.LmazeEnv_v5
+LmazeEnv_v6 = _impl.LmazeEnv_v6

@@ -186,7 +186,9 @@ int lmaze_render_expanded(const int32_t* obs, int32_t grid, int32_t expansion,
 enum {
     LMAZE_VARIANT_V1 = 1, /* LmazeEnv_v1 (v1:114-200): 4-neighbour move, two reward streams, foveal goal */
     LMAZE_VARIANT_V2 = 2, /* LmazeEnv_v2 (v2:127-225): 25-way teleport inside the fovea, 5 layouts       */
-    LMAZE_VARIANT_V4 = 4  /* LmazeEnv_v4 (v4:167-272): v2 + float visit-map plane                        */
+    LMAZE_VARIANT_V4 = 4, /* LmazeEnv_v4 (v4:167-272): v2 + float visit-map plane                        */
+    LMAZE_VARIANT_V5 = 5, /* LmazeEnv_v5 (v5:187-292): two-level planner / local loop, 8-tuple return    */
+    LMAZE_VARIANT_V6 = 6  /* LmazeEnv_v6: v5 + safeFovealGoal (v6:505-523); same step rules             */
 };
 
 #define LMAZE_FOVEA 5
@@ -196,8 +198,10 @@ typedef struct LmazeFovealParams {
     int32_t variant;            /* LMAZE_VARIANT_V1 / V2 / V4                                          */
     int32_t grid;               /* G (v1: 14, v1:22; v2/v4: 18)                                        */
     int32_t n_layouts;          /* rows of the layout table uint8[L,G,G] (v1: 1; v2/v4: 5, v2:309-405) */
-    int32_t step_limit;         /* v1: done at stepCount == 200 (v1:295); v2/v4: > 50 (v2:222)         */
-    int32_t foveal_step_limit;  /* v1: fovealStepCount == 10 (v1:309); unused by v2/v4                 */
+    int32_t step_limit;         /* v1: done at stepCount == 200 (v1:295); v2/v4: > 50 (v2:222);
+                                   v5/v6: localDone at stepCount >= 10 (v5:45,267)                     */
+    int32_t foveal_step_limit;  /* v1: fovealStepCount == 10 (v1:309); v5/v6: >= 50 ends the episode
+                                   (v5:46,269-271); unused by v2/v4                                    */
     float reward_wall;          /* negativeNominal -1.0                                                 */
     float reward_move;          /* positiveNominal v1 +0.01 (v1:28); v2/v4 -0.01 (v2:47)               */
     float reward_goal;          /* positiveFull    v1 1.0 (v1:29);   v2/v4 100.0                       */
@@ -215,8 +219,15 @@ typedef struct LmazeFovealBuffers {
     float* foveal_reward;       /* [N]   fovealReward               v1                                  */
     uint8_t* done;              /* [N]                                                                  */
     uint8_t* foveal_done;       /* [N]   isFovealEpisodeFinished()  v1 (v1:308-324)                     */
-    float* visit;               /* [N,G,G] visit map state[2]       v4 (v4:116-119,211-214)             */
-    float* obs;                 /* [N,C,5,5], 16-byte aligned                                           */
+    float* visit;               /* [N,G,G] visit map state[2]       v4, v5, v6 (v4:116-119, v5:313-318) */
+    float* obs;                 /* [N,C,5,5], 16-byte aligned (v5/v6: the foveal observation, C = 7)    */
+    /* v5 / v6 only (v5:62-78).  For them: reward = globalReward, foveal_reward = originalReward (the
+     * local stream), done = globalDone, foveal_done = localDone, fgoal_xy = f_goal_x0/y0.               */
+    int32_t* ball1_xy;          /* [N,2] ball_x1, ball_y1 (previous ball, v5:193-194)                   */
+    int32_t* fovea_xy;          /* [N,4] fovea_x0, fovea_y0, fovea_x1, fovea_y1                         */
+    int32_t* last_xy;           /* [N,2] window centre `retStatelast` is a view of (v5:322-323,344-346) */
+    int32_t* foveal_goal;       /* [N]   index 0..24 of the one-hot fovealGoal plane (v5:166-169)        */
+    float* obs_local;           /* [N,4,5,5] buildLocalObservation (v5:356-380), 16-byte aligned        */
 } LmazeFovealBuffers;
 
 /*
@@ -252,6 +263,31 @@ int lmaze_foveal_reset(const LmazeFovealParams* params, const uint8_t* layouts, 
  */
 int lmaze_v1_set_foveal_goal(const LmazeFovealParams* params, const uint8_t* layouts, const int32_t* ij,
                              const uint8_t* mask, const LmazeFovealBuffers* bufs, int64_t n, void* stream);
+
+/*
+ * v5/v6 plannerStep(goal) (v5:158-182) for the envs with mask[i] != 0 (NULL = all):
+ * stepCount = 0, globalReward = -0.0, localDone = False, foveal goal = ball + (goal/5, goal%5) - 2,
+ * fovea history shifted once fovealStepCount > 0, fovealStepCount += 1, obs_local written.
+ * goal int32[N] in 0..24; the reference raises IndexError half-way through for any other value,
+ * here such an env is left untouched.  lmaze_foveal_step / lmaze_foveal_reset take these variants
+ * too: step() = v5:187-292 with actions 0:(+1,0) 1:(-1,0) 2:(0,+1) 3:(0,-1) (v5:205-217; the
+ * opposite sign convention to v0), writing obs (foveal, v5:306-348) and obs_local.  Where the
+ * reference's buildLocalObservation indexes outside its 5x5 frame (ball more than 2 cells right /
+ * below fovea_1) it raises IndexError AFTER the state was updated; the kernel leaves that one-hot
+ * plane empty and the state is the reference's.
+ */
+int lmaze_v5_planner_step(const LmazeFovealParams* params, const uint8_t* layouts, const int32_t* goal,
+                          const uint8_t* mask, const LmazeFovealBuffers* bufs, int64_t n, void* stream);
+
+/*
+ * v6 safeFovealGoal() (v6:505-523): for every env one window cell index 0..24 drawn uniformly from the
+ * cells of the 5x5 window around the ball that are not 'W' (the reference rejects on np.random; here
+ * Philox keyed by (seed, env_base + i, epoch), index (r*count)>>32 among the accepted cells in
+ * row-major order).  out_goal int32[N].
+ */
+int lmaze_v6_safe_foveal_goal(const LmazeFovealParams* params, const uint8_t* layouts, uint64_t seed,
+                              uint64_t epoch, int64_t env_base, const LmazeFovealBuffers* bufs,
+                              int32_t* out_goal, int64_t n, void* stream);
 
 /*
  * The xE nearest-neighbour loop on float planes (v1:258-277, v2:197-203, v4:243-249):

@@ -430,7 +430,122 @@ def gen_v1():
     save("v1_scripted_goal", rollout_v1(acts, fg3, seed=3))
 
 
-GENERATORS = {"v0": gen_v0, "v3": gen_v3, "v1": gen_v1, "v2": gen_v2, "v4": gen_v4}
+# ----------------------------------------------------------------------------------------
+# v5 / v6 (lmaze_env_v5.py, lmaze_env_v6.py): two-level planner / local loop.  The rollout is a
+# sequence of EVENTS (reset, plannerStep(g), step(a)); after every event the full state is recorded.
+# ----------------------------------------------------------------------------------------
+EV_RESET, EV_PLANNER, EV_STEP = 0, 1, 2
+
+
+def rollout_v56(variant, n_events, seed, safe_goals=False, calm=False):
+    import contextlib
+    import io
+    rs = np.random.RandomState(seed + 1000)
+    random.seed(seed)
+    np.random.seed(seed)
+    five_layouts()
+    env = ref_loader.make(variant)
+    E = env.expansionRatio
+    T = n_events
+    rec = dict(E=np.int32(E), seed=np.int64(seed), layouts=five_layouts(),
+               ev_type=np.zeros(T, np.int32), ev_arg=np.zeros(T, np.int32), raised=np.zeros(T, np.uint8),
+               ball0=np.zeros((T, 2), np.int32), ball1=np.zeros((T, 2), np.int32), goal=np.zeros((T, 2), np.int32),
+               fgoal=np.zeros((T, 2), np.int32), fovea0=np.zeros((T, 2), np.int32), fovea1=np.zeros((T, 2), np.int32),
+               layout_id=np.zeros(T, np.int32), step_count=np.zeros(T, np.int32),
+               foveal_step_count=np.zeros(T, np.int32),
+               global_reward=np.zeros(T, np.float64), local_reward=np.zeros(T, np.float64),
+               global_done=np.zeros(T, np.uint8), local_done=np.zeros(T, np.uint8),
+               visit=np.zeros((T, 18, 18), np.float32),
+               fov_planes=np.zeros((T, 7, 5, 5), np.float32), loc_planes=np.zeros((T, 4, 5, 5), np.float32),
+               fov_hash=np.zeros(T, np.uint64), loc_hash=np.zeros(T, np.uint64),
+               fgoal_plane=np.zeros((T, 5, 5), np.float32))
+    state = "reset"
+    extra = 0
+    for t in range(T):
+        fov = loc = None
+        try:
+            if state == "reset":
+                rec["ev_type"][t] = EV_RESET
+                fov = env.reset()
+                state = "planner" if rs.rand() < 0.9 else "step"     # sometimes step() before any plannerStep
+            elif state == "planner":
+                rec["ev_type"][t] = EV_PLANNER
+                if safe_goals and rs.rand() < 0.7:
+                    g = int(env.safeFovealGoal())                    # v6:505-523 (np.random stream)
+                else:
+                    g = int(rs.randint(0, 25))
+                rec["ev_arg"][t] = g
+                loc = env.plannerStep(g)
+                state = "step"
+            else:
+                rec["ev_type"][t] = EV_STEP
+                a = int(rs.randint(0, 4)) if rs.rand() < 0.93 else int(rs.randint(-1, 7))
+                if calm:                                             # back-and-forth: never walks off the 5x5 frame,
+                    a = (0, 1, 2, 3)[t % 4]                          # so fovealStepCount reaches its limit of 50
+                rec["ev_arg"][t] = a
+                with contextlib.redirect_stdout(io.StringIO()):
+                    out = env.step(a)
+                fov, loc = out[0], out[1]
+                assert out[2] == env.globalReward and out[3] == env.originalReward
+                assert out[4] == env.globalDone and out[5] == env.localDone and out[7] == a
+                assert (out[6] == env.fovealGoal).all() and out[6].shape == (1, 5, 5)
+                if env.globalDone:
+                    state = "reset"
+                elif env.localDone:
+                    if extra == 0 and rs.rand() < 0.25:
+                        extra = int(rs.randint(1, 3))                # a few more steps with localDone still set
+                    if extra > 0:
+                        extra -= 1
+                        state = "step" if extra > 0 else "planner"
+                    else:
+                        state = "planner"
+        except IndexError:
+            rec["raised"][t] = 1                                     # buildLocalObservation indexed outside 5x5
+            state = "reset"
+        rec["ball0"][t] = (env.ball_x0, env.ball_y0)
+        rec["ball1"][t] = (env.ball_x1, env.ball_y1)
+        rec["goal"][t] = (env.goal_x, env.goal_y)
+        rec["fgoal"][t] = (env.f_goal_x0, env.f_goal_y0)
+        rec["fovea0"][t] = (env.fovea_x0, env.fovea_y0)
+        rec["fovea1"][t] = (env.fovea_x1, env.fovea_y1)
+        rec["layout_id"][t] = layout_id_of(env.grid)
+        rec["step_count"][t] = env.stepCount
+        rec["foveal_step_count"][t] = env.fovealStepCount
+        rec["global_reward"][t] = env.globalReward
+        rec["local_reward"][t] = env.originalReward
+        rec["global_done"][t] = env.globalDone
+        rec["local_done"][t] = env.localDone
+        rec["visit"][t] = env.state[2]
+        rec["fgoal_plane"][t] = env.fovealGoal[0]
+        if fov is not None:
+            rec["fov_planes"][t] = unexpand(fov, E)
+            rec["fov_hash"][t] = obs_hash(fov)
+        if loc is not None:
+            rec["loc_planes"][t] = unexpand(loc, E)
+            rec["loc_hash"][t] = obs_hash(loc)
+    return rec
+
+
+def save_events(name, rec):
+    os.makedirs(OUT, exist_ok=True)
+    path = os.path.join(OUT, name + ".npz")
+    np.savez_compressed(path, **rec)
+    print("wrote %-28s events=%d raised=%d  %.1f KB" % (name, len(rec["ev_type"]), int(rec["raised"].sum()),
+                                                        os.path.getsize(path) / 1024.0))
+
+
+def gen_v5():
+    save_events("v5_seed0", rollout_v56("v5", 700, seed=0))
+    save_events("v5_seed1", rollout_v56("v5", 500, seed=1))
+    save_events("v5_calm_seed3", rollout_v56("v5", 700, seed=3, calm=True))
+
+
+def gen_v6():
+    save_events("v6_seed0", rollout_v56("v6", 600, seed=0, safe_goals=True))
+    save_events("v6_seed2", rollout_v56("v6", 400, seed=2, safe_goals=True))
+
+
+GENERATORS = {"v0": gen_v0, "v3": gen_v3, "v1": gen_v1, "v2": gen_v2, "v4": gen_v4, "v5": gen_v5, "v6": gen_v6}
 
 if __name__ == "__main__":
     which = sys.argv[1:] or sorted(GENERATORS)

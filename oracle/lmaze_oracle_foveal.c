@@ -283,3 +283,213 @@ int lmaze_oracle_expand_planes(const float* planes, int32_t channels, int32_t g,
     }
     return 0;
 }
+
+/* ====================================================================================== */
+/* v5 / v6: gym_lmaze/envs/lmaze_env_v5.py (v6 = v5 + safeFovealGoal, lmaze_env_v6.py:505-523) */
+/* ====================================================================================== */
+static int check_v56(const LmazeFovealParams* p, const uint8_t* layouts, const LmazeFovealBuffers* b, int64_t n) {
+    if (!p || !layouts || !b) return LMAZE_E_NULL;
+    if (p->variant != LMAZE_VARIANT_V5 && p->variant != LMAZE_VARIANT_V6) return LMAZE_E_VARIANT;
+    if (p->grid < F || p->grid > LMAZE_MAX_GRID) return LMAZE_E_GRID;
+    if (p->n_layouts < 1 || p->n_layouts > LMAZE_MAX_LAYOUTS) return LMAZE_E_LAYOUT;
+    if (n < 0) return LMAZE_E_COUNT;
+    if (!b->ball_xy || !b->goal_xy || !b->fgoal_xy || !b->layout_id || !b->step_count || !b->foveal_step_count ||
+        !b->reward || !b->foveal_reward || !b->done || !b->foveal_done || !b->visit || !b->obs || !b->ball1_xy ||
+        !b->fovea_xy || !b->last_xy || !b->foveal_goal || !b->obs_local)
+        return LMAZE_E_NULL;
+    return 0;
+}
+
+/* numpy index semantics on an axis of 5: -5..-1 wrap, anything else outside 0..4 raises (-> -1) */
+static int wrap5(int i) {
+    if (i >= 0 && i < F) return i;
+    if (i < 0 && i >= -F) return i + F;
+    return -1;
+}
+
+/* v5:306-348.  fov = [window3(fovea0), fovealGoal plane, window3(last)]; visit sampled live. */
+static void fov_obs_v5(const uint8_t* lay, int G, int f0x, int f0y, int lx, int ly, int gx, int gy, int fg,
+                       const float* visit, float* o) {
+    view_v24(LMAZE_VARIANT_V4, lay, G, f0x, f0y, lx, ly, gx, gy, -1, visit, o);
+    for (int c = 0; c < W25; ++c) o[3 * W25 + c] = (c == fg) ? 1.0f : 0.0f;   /* v5:166-169 one-hot */
+}
+
+/* v5:356-380 */
+static void loc_obs_v5(const uint8_t* lay, int G, int f0x, int f0y, int f1x, int f1y, int b0x, int b0y, int b1x,
+                       int b1y, int fg, float* o) {
+    for (int i = 0; i < F; ++i)
+        for (int j = 0; j < F; ++j) {
+            const int x = f0x - 2 + i, y = f0y - 2 + j;
+            const int in = x >= 0 && y >= 0 && x < G && y < G;
+            o[0 * W25 + i * F + j] = in ? free_plane(lay[x * G + y]) : 0.0f;   /* v5:361 */
+            o[1 * W25 + i * F + j] = 0.0f;
+            o[2 * W25 + i * F + j] = 0.0f;
+            o[3 * W25 + i * F + j] = (i * F + j == fg) ? 1.0f : 0.0f;           /* v5:368 */
+        }
+    int i = wrap5(b0x - f1x + 2), j = wrap5(b0y - f1y + 2);                     /* v5:364 */
+    if (i >= 0 && j >= 0) o[1 * W25 + i * F + j] = 1.0f;
+    i = wrap5(b1x - f1x + 2); j = wrap5(b1y - f1y + 2);                         /* v5:365 */
+    if (i >= 0 && j >= 0) o[2 * W25 + i * F + j] = 1.0f;
+}
+
+int lmaze_oracle_v5_step(const LmazeFovealParams* p, const uint8_t* layouts, const int32_t* action,
+                         const LmazeFovealBuffers* b, int64_t n) {
+    int rc = check_v56(p, layouts, b, n);
+    if (rc) return rc;
+    if (!action) return LMAZE_E_NULL;
+    const int G = p->grid;
+#pragma omp parallel for schedule(static)
+    for (int64_t e = 0; e < n; ++e) {
+        const uint8_t* lay = layouts + (size_t)b->layout_id[e] * G * G;
+        float* visit = b->visit + (size_t)e * G * G;
+        const int a = action[e];
+        int b0x = b->ball_xy[2 * e], b0y = b->ball_xy[2 * e + 1];
+        const int b1x = b0x, b1y = b0y;                            /* v5:193-194 */
+        const int gx = b->goal_xy[2 * e], gy = b->goal_xy[2 * e + 1];
+        const int fgx = b->fgoal_xy[2 * e], fgy = b->fgoal_xy[2 * e + 1];
+        const int f1x = b->fovea_xy[4 * e + 2], f1y = b->fovea_xy[4 * e + 3];
+        const int fsc = b->foveal_step_count[e];
+        int ld = b->foveal_done[e], gd = b->done[e];               /* both persist across step() calls */
+        float lr = -0.0f, gr;                                      /* v5:196 */
+        const int sc = b->step_count[e] + 1;                       /* v5:197 */
+        int dx = 0, dy = 0;                                        /* v5:205-217 */
+        if (a == 0) dx = 1; else if (a == 1) dx = -1; else if (a == 2) dy = 1; else if (a == 3) dy = -1;
+        const int nx = b0x + dx, ny = b0y + dy;
+        const uint8_t c = cell_at(lay, G, nx, ny);
+        if (c == 'W') {                                            /* v5:232-233 */
+            lr = p->reward_wall;
+        } else if (nx == fgx && ny == fgy) {                       /* v5:235-239 */
+            lr = p->reward_goal; b0x = nx; b0y = ny; ld = 1;
+        } else if (c == 'B' || c == 'S' || c == 'X') {             /* v5:241-248 */
+            if (nx < f1x - 3 || nx > f1x + 2 || ny < f1y - 3 || ny > f1y + 2) ld = 1;
+            lr = p->reward_move; b0x = nx; b0y = ny;
+        }
+        if (nx == gx && ny == gy) { gr = p->reward_goal; gd = 1; } /* v5:254-262, judged on the projected cell */
+        else if (nx == fgx && ny == fgy) gr = p->reward_move;
+        else gr = p->reward_wall;
+        const int f0x = b0x, f0y = b0y;                            /* v5:264-265 */
+        if (sc >= p->step_limit) ld = 1;                           /* v5:267 */
+        if (fsc >= p->foveal_step_limit) { gd = 1; ld = 1; }       /* v5:269-271 */
+        int lx = b->last_xy[2 * e], ly = b->last_xy[2 * e + 1];
+        if (ld) visit_update(visit, G, f0x, f0y);                  /* v5:313-318 */
+        if (fsc == 0) { lx = f0x; ly = f0y; }                      /* v5:322-323 */
+        fov_obs_v5(lay, G, f0x, f0y, lx, ly, gx, gy, b->foveal_goal[e], visit, b->obs + (size_t)e * 7 * W25);
+        if (ld) { lx = f0x; ly = f0y; }                            /* v5:344-346 */
+        loc_obs_v5(lay, G, f0x, f0y, f1x, f1y, b0x, b0y, b1x, b1y, b->foveal_goal[e], b->obs_local + (size_t)e * 4 * W25);
+        b->ball_xy[2 * e] = b0x; b->ball_xy[2 * e + 1] = b0y;
+        b->ball1_xy[2 * e] = b1x; b->ball1_xy[2 * e + 1] = b1y;
+        b->fovea_xy[4 * e] = f0x; b->fovea_xy[4 * e + 1] = f0y;
+        b->last_xy[2 * e] = lx; b->last_xy[2 * e + 1] = ly;
+        b->step_count[e] = sc;
+        b->reward[e] = gr; b->foveal_reward[e] = lr;
+        b->done[e] = (uint8_t)gd; b->foveal_done[e] = (uint8_t)ld;
+    }
+    return 0;
+}
+
+int lmaze_oracle_v5_planner_step(const LmazeFovealParams* p, const uint8_t* layouts, const int32_t* goal,
+                                 const uint8_t* mask, const LmazeFovealBuffers* b, int64_t n) {
+    int rc = check_v56(p, layouts, b, n);
+    if (rc) return rc;
+    if (!goal) return LMAZE_E_NULL;
+    const int G = p->grid;
+#pragma omp parallel for schedule(static)
+    for (int64_t e = 0; e < n; ++e) {
+        if (mask && !mask[e]) continue;
+        const int g = goal[e];
+        if (g < 0 || g >= W25) continue;                           /* the reference raises half-way (v5:169) */
+        const uint8_t* lay = layouts + (size_t)b->layout_id[e] * G * G;
+        const int b0x = b->ball_xy[2 * e], b0y = b->ball_xy[2 * e + 1];
+        b->step_count[e] = 0;                                      /* v5:160 */
+        b->reward[e] = -0.0f;                                      /* v5:161 globalReward */
+        b->foveal_done[e] = 0;                                     /* v5:162 localDone */
+        b->foveal_goal[e] = g;                                     /* v5:166-169 */
+        b->fgoal_xy[2 * e] = b0x + g / F - 2;                      /* v5:172-173 */
+        b->fgoal_xy[2 * e + 1] = b0y + g % F - 2;
+        if (b->foveal_step_count[e] > 0) {                         /* v5:175-177 */
+            b->fovea_xy[4 * e + 2] = b->fovea_xy[4 * e];
+            b->fovea_xy[4 * e + 3] = b->fovea_xy[4 * e + 1];
+        }
+        b->foveal_step_count[e] += 1;                              /* v5:179 */
+        loc_obs_v5(lay, G, b->fovea_xy[4 * e], b->fovea_xy[4 * e + 1], b->fovea_xy[4 * e + 2], b->fovea_xy[4 * e + 3],
+                   b0x, b0y, b->ball1_xy[2 * e], b->ball1_xy[2 * e + 1], g, b->obs_local + (size_t)e * 4 * W25);
+    }
+    return 0;
+}
+
+/* reset(), v5:104-150; placement as v4 (setGrid first, v5:105) when place != 0 */
+int lmaze_oracle_v5_reset(const LmazeFovealParams* p, const uint8_t* layouts, const uint8_t* mask, int32_t place,
+                          uint64_t seed, uint64_t epoch, int64_t env_base, const LmazeFovealBuffers* b, int64_t n) {
+    int rc = check_v56(p, layouts, b, n);
+    if (rc) return rc;
+    const int G = p->grid, L = p->n_layouts;
+#pragma omp parallel for schedule(static)
+    for (int64_t e = 0; e < n; ++e) {
+        if (mask && !mask[e]) continue;
+        if (place) {
+            const uint64_t ge = (uint64_t)(env_base + e);
+            uint32_t ctr[4] = {(uint32_t)ge, (uint32_t)(ge >> 32), (uint32_t)epoch, (uint32_t)(epoch >> 32)};
+            uint32_t key[2] = {(uint32_t)seed, (uint32_t)(seed >> 32)};
+            uint32_t r[4];
+            lmaze_oracle_philox4x32_10(ctr, key, r);
+            const int lid = (int)(((uint64_t)r[2] * (uint32_t)L) >> 32);
+            const uint8_t* lay = layouts + (size_t)lid * G * G;
+            b->layout_id[e] = lid;
+            const int cg = count_or_kth(lay, G, 0, -1, -1);
+            int goal_cell = -1;
+            if (cg > 0) {
+                goal_cell = count_or_kth(lay, G, 0, -1, (int)(((uint64_t)r[0] * (uint32_t)cg) >> 32));
+                b->goal_xy[2 * e] = goal_cell / G; b->goal_xy[2 * e + 1] = goal_cell % G;
+            }
+            const int cb = count_or_kth(lay, G, 1, goal_cell, -1);
+            if (cb > 0) {
+                const int cell = count_or_kth(lay, G, 1, goal_cell, (int)(((uint64_t)r[1] * (uint32_t)cb) >> 32));
+                b->ball_xy[2 * e] = cell / G; b->ball_xy[2 * e + 1] = cell % G;
+            }
+        }
+        const uint8_t* lay = layouts + (size_t)b->layout_id[e] * G * G;
+        const int bx = b->ball_xy[2 * e], by = b->ball_xy[2 * e + 1];
+        b->foveal_reward[e] = -0.0f; b->reward[e] = -0.0f;         /* v5:107-108 */
+        b->foveal_step_count[e] = 0; b->step_count[e] = 0;         /* v5:109-110 */
+        b->done[e] = 0; b->foveal_done[e] = 0;                     /* v5:111-112 */
+        b->foveal_goal[e] = 12;                                    /* v5:127-128 one-hot at the centre */
+        float* visit = b->visit + (size_t)e * G * G;
+        memset(visit, 0, sizeof(float) * (size_t)G * G);           /* v5:130 */
+        b->fovea_xy[4 * e] = bx; b->fovea_xy[4 * e + 1] = by;      /* v5:136-143 */
+        b->fovea_xy[4 * e + 2] = bx; b->fovea_xy[4 * e + 3] = by;
+        b->fgoal_xy[2 * e] = bx; b->fgoal_xy[2 * e + 1] = by;
+        b->ball1_xy[2 * e] = bx; b->ball1_xy[2 * e + 1] = by;
+        b->last_xy[2 * e] = bx; b->last_xy[2 * e + 1] = by;        /* fovealStepCount == 0, v5:322 */
+        fov_obs_v5(lay, G, bx, by, bx, by, b->goal_xy[2 * e], b->goal_xy[2 * e + 1], 12, visit, b->obs + (size_t)e * 7 * W25);
+    }
+    return 0;
+}
+
+/* v6:505-523 */
+int lmaze_oracle_v6_safe_foveal_goal(const LmazeFovealParams* p, const uint8_t* layouts, uint64_t seed, uint64_t epoch,
+                                     int64_t env_base, const LmazeFovealBuffers* b, int32_t* out_goal, int64_t n) {
+    int rc = check_v56(p, layouts, b, n);
+    if (rc) return rc;
+    if (!out_goal) return LMAZE_E_NULL;
+    const int G = p->grid;
+#pragma omp parallel for schedule(static)
+    for (int64_t e = 0; e < n; ++e) {
+        const uint8_t* lay = layouts + (size_t)b->layout_id[e] * G * G;
+        const int bx = b->ball_xy[2 * e], by = b->ball_xy[2 * e + 1];
+        const uint64_t ge = (uint64_t)(env_base + e);
+        uint32_t ctr[4] = {(uint32_t)ge, (uint32_t)(ge >> 32), (uint32_t)epoch, (uint32_t)(epoch >> 32)};
+        uint32_t key[2] = {(uint32_t)seed, (uint32_t)(seed >> 32)};
+        uint32_t r[4];
+        lmaze_oracle_philox4x32_10(ctr, key, r);
+        int cnt = 0;
+        for (int c = 0; c < W25; ++c) cnt += cell_at(lay, G, bx - 2 + c / F, by - 2 + c % F) != 'W';
+        int pick = 12;
+        if (cnt > 0) {
+            int k = (int)(((uint64_t)r[0] * (uint32_t)cnt) >> 32);
+            for (int c = 0; c < W25; ++c)
+                if (cell_at(lay, G, bx - 2 + c / F, by - 2 + c % F) != 'W') { if (k == 0) { pick = c; break; } --k; }
+        }
+        out_goal[e] = pick;
+    }
+    return 0;
+}

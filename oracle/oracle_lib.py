@@ -129,8 +129,8 @@ def philox4x32_10(ctr, key):
 # ---------------------------------------------------------------------------------------
 # foveal variants (lmaze_oracle_foveal.c)
 # ---------------------------------------------------------------------------------------
-VARIANT_V1, VARIANT_V2, VARIANT_V4 = 1, 2, 4
-FOVEAL_CHANNELS = {VARIANT_V1: 4, VARIANT_V2: 5, VARIANT_V4: 7}
+VARIANT_V1, VARIANT_V2, VARIANT_V4, VARIANT_V5, VARIANT_V6 = 1, 2, 4, 5, 6
+FOVEAL_CHANNELS = {VARIANT_V1: 4, VARIANT_V2: 5, VARIANT_V4: 7, VARIANT_V5: 7, VARIANT_V6: 7}
 
 
 class FovealParams(C.Structure):
@@ -142,12 +142,15 @@ class FovealParams(C.Structure):
 class FovealBuffers(C.Structure):
     _fields_ = [(n, C.c_void_p) for n in ("ball_xy", "goal_xy", "fgoal_xy", "layout_id", "step_count",
                                           "foveal_step_count", "reward", "foveal_reward", "done", "foveal_done",
-                                          "visit", "obs")]
+                                          "visit", "obs", "ball1_xy", "fovea_xy", "last_xy", "foveal_goal",
+                                          "obs_local")]
 
 
 def foveal_params(variant, grid, n_layouts):
     if variant == VARIANT_V1:      # lmaze_env_v1.py:22-29
         return FovealParams(variant, grid, n_layouts, 200, 10, -1.0, 0.01, 1.0)
+    if variant in (VARIANT_V5, VARIANT_V6):   # lmaze_env_v5.py:45-49
+        return FovealParams(variant, grid, n_layouts, 10, 50, -1.0, -0.01, 100.0)
     return FovealParams(variant, grid, n_layouts, 50, 0, -1.0, -0.01, 100.0)   # lmaze_env_v2.py:43-49
 
 
@@ -168,6 +171,11 @@ class FovealState(object):
         self.foveal_done = np.zeros(n, np.uint8)
         self.visit = np.zeros((n, grid, grid), np.float32)
         self.obs = np.zeros((n, Cn, 5, 5), np.float32)
+        self.ball1_xy = np.zeros((n, 2), np.int32)
+        self.fovea_xy = np.zeros((n, 4), np.int32)
+        self.last_xy = np.zeros((n, 2), np.int32)
+        self.foveal_goal = np.zeros(n, np.int32)
+        self.obs_local = np.zeros((n, 4, 5, 5), np.float32)
         self.n = n
 
     def struct(self):
@@ -208,4 +216,38 @@ def expand_planes(planes, expansion):
                                           _p(out, C.c_float), C.c_int64(n))
     if rc:
         raise RuntimeError("lmaze_oracle_expand_planes -> %d" % rc)
+    return out
+
+
+def v5_step(p, layouts, action, st):
+    b = st.struct()
+    rc = lib().lmaze_oracle_v5_step(C.byref(p), _p(layouts, C.c_uint8), _p(action, C.c_int32), C.byref(b), C.c_int64(st.n))
+    if rc:
+        raise RuntimeError("lmaze_oracle_v5_step -> %d" % rc)
+
+
+def v5_planner_step(p, layouts, goal, mask, st):
+    b = st.struct()
+    goal = np.ascontiguousarray(goal, dtype=np.int32)
+    rc = lib().lmaze_oracle_v5_planner_step(C.byref(p), _p(layouts, C.c_uint8), _p(goal, C.c_int32), _p(mask, C.c_uint8),
+                                            C.byref(b), C.c_int64(st.n))
+    if rc:
+        raise RuntimeError("lmaze_oracle_v5_planner_step -> %d" % rc)
+
+
+def v5_reset(p, layouts, mask, place, seed, epoch, st, env_base=0):
+    b = st.struct()
+    rc = lib().lmaze_oracle_v5_reset(C.byref(p), _p(layouts, C.c_uint8), _p(mask, C.c_uint8), C.c_int32(place),
+                                     C.c_uint64(seed), C.c_uint64(epoch), C.c_int64(env_base), C.byref(b), C.c_int64(st.n))
+    if rc:
+        raise RuntimeError("lmaze_oracle_v5_reset -> %d" % rc)
+
+
+def v6_safe_foveal_goal(p, layouts, seed, epoch, st, env_base=0):
+    b = st.struct()
+    out = np.zeros(st.n, np.int32)
+    rc = lib().lmaze_oracle_v6_safe_foveal_goal(C.byref(p), _p(layouts, C.c_uint8), C.c_uint64(seed), C.c_uint64(epoch),
+                                                C.c_int64(env_base), C.byref(b), _p(out, C.c_int32), C.c_int64(st.n))
+    if rc:
+        raise RuntimeError("lmaze_oracle_v6_safe_foveal_goal -> %d" % rc)
     return out

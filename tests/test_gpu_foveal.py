@@ -258,3 +258,145 @@ def test_dropin_v1_six_tuple():
         assert obs_hash(o) == g["obs_hash"][t], t
         assert env.isEpisodeFinished() == d and env.fovealStepCount == g["foveal_step_count"][t]
     assert (env.goal_x, env.goal_y) == tuple(g["goal"])
+
+
+# ---------------------------------------------------------------- v5 / v6 (two-level loop)
+def _check_v56(env, g, t):
+    h = env.host_state()
+    assert tuple(h["ball_xy"][0]) == tuple(g["ball0"][t]) and tuple(h["ball1_xy"][0]) == tuple(g["ball1"][t]), t
+    assert tuple(h["goal_xy"][0]) == tuple(g["goal"][t]) and tuple(h["fgoal_xy"][0]) == tuple(g["fgoal"][t]), t
+    assert tuple(h["fovea_xy"][0]) == tuple(g["fovea0"][t]) + tuple(g["fovea1"][t]), t
+    assert h["layout_id"][0] == g["layout_id"][t], t
+    assert h["step_count"][0] == g["step_count"][t] and h["foveal_step_count"][0] == g["foveal_step_count"][t], t
+    assert f32_bits(h["reward"])[0] == ref_reward_bits(g["global_reward"][t]), t
+    assert f32_bits(h["foveal_reward"])[0] == ref_reward_bits(g["local_reward"][t]), t
+    assert h["done"][0] == g["global_done"][t] and h["foveal_done"][0] == g["local_done"][t], t
+    assert (_bits(_np(env.visit)[0]) == _bits(g["visit"][t])).all(), t
+    plane = np.zeros(25, np.float32)
+    plane[h["foveal_goal"][0]] = 1.0
+    assert (plane.reshape(5, 5) == g["fgoal_plane"][t]).all(), t
+
+
+@pytest.mark.parametrize("name", golden_files("v5_") + golden_files("v6_"))
+def test_hip_v56_matches_reference_fixture(name):
+    g = load_golden(name)
+    env = PKG.LmazeFovealVecEnv(1, variant="v5", layouts=list(g["layouts"]), reset=False)
+    E = int(g["E"])
+    for t in range(len(g["ev_type"])):
+        ev, arg = int(g["ev_type"][t]), int(g["ev_arg"][t])
+        if ev == 0:
+            env.set_state(ball_xy=g["ball0"][t:t + 1], goal_xy=g["goal"][t:t + 1], layout_id=g["layout_id"][t:t + 1])
+            env.reset(place=False)
+        elif ev == 1:
+            env.planner_step([arg])
+        else:
+            env.step([arg])
+        _check_v56(env, g, t)
+        if g["raised"][t]:
+            continue
+        if ev in (0, 2):
+            assert (_bits(_np(env.obs)[0]) == _bits(g["fov_planes"][t])).all(), t
+            assert obs_hash(_np(env.expanded())[0]) == g["fov_hash"][t], t
+        if ev in (1, 2):
+            assert (_bits(_np(env.obs_local)[0]) == _bits(g["loc_planes"][t])).all(), t
+            assert obs_hash(_np(env.expanded_local())[0]) == g["loc_hash"][t], t
+
+
+def _mirror56(env):
+    st = O.FovealState(O.VARIANT_V5, env.num_envs, env.grid)
+    h = env.host_state()
+    for k in h:
+        getattr(st, k)[...] = h[k]
+    st.visit[...] = _np(env.visit)
+    st.obs[...] = _np(env.obs)
+    st.obs_local[...] = _np(env.obs_local)
+    return st
+
+
+def _same56(env, st, tag):
+    h = env.host_state()
+    for k in h:
+        a, b = h[k], getattr(st, k)
+        assert (np.ascontiguousarray(a).view(np.uint8) == np.ascontiguousarray(b).view(np.uint8)).all(), (k, tag)
+    assert (_bits(_np(env.visit)) == _bits(st.visit)).all(), tag
+    assert (_bits(_np(env.obs)) == _bits(st.obs)).all(), tag
+    assert (_bits(_np(env.obs_local)) == _bits(st.obs_local)).all(), tag
+
+
+@pytest.mark.parametrize("N", [1, 33, 1000])
+def test_v56_batched_two_level_loop_vs_oracle(N):
+    seed = 7 + N
+    env = PKG.LmazeFovealVecEnv(N, variant="v6", seed=seed, env_base=11)
+    lay = _np(env.layouts)
+    p = O.foveal_params(O.VARIANT_V6, env.grid, env.n_layouts)
+    st = O.FovealState(O.VARIANT_V6, N, env.grid)
+    O.v5_reset(p, lay, None, 1, seed, 0, st, env_base=11)
+    st.obs_local[...] = _np(env.obs_local)
+    _same56(env, st, "reset")
+    rs = np.random.RandomState(N)
+    epoch = 1
+    for t in range(60):
+        # planner step for the envs whose local episode ended (all at t = 0)
+        m = np.ones(N, np.uint8) if t == 0 else st.foveal_done.copy()
+        if t % 2 == 0:
+            goal = _np(env.safe_foveal_goal())
+            ref = O.v6_safe_foveal_goal(p, lay, seed, epoch, st, env_base=11)
+            epoch += 1
+            assert (goal == ref).all()
+        else:
+            goal = np.where(rs.rand(N) < 0.95, rs.randint(0, 25, N), rs.randint(-2, 28, N)).astype(np.int32)
+        env.planner_step(goal, mask=torch.from_numpy(m))
+        O.v5_planner_step(p, lay, goal, m, st)
+        _same56(env, st, ("planner", t))
+        for k in range(3):
+            a = np.where(rs.rand(N) < 0.9, rs.randint(0, 4, N), rs.randint(-1, 6, N)).astype(np.int32)
+            env.step(torch.from_numpy(a))
+            O.v5_step(p, lay, a, st)
+            _same56(env, st, ("step", t, k))
+        if t % 5 == 4:
+            m = st.done.copy()
+            env.reset(mask=torch.from_numpy(m))
+            O.v5_reset(p, lay, m, 1, seed, epoch, st, env_base=11)
+            epoch += 1
+            _same56(env, st, ("reset", t))
+
+
+def test_dropin_v6_seeded_event_rollout():
+    """The reference's usage loop on the drop-in object: same `random` / `np.random` draws (placement,
+    safeFovealGoal), same 8-tuples, IndexError where the reference raises."""
+    import random
+    import gym_lmaze
+    g = load_golden("v6_seed0")
+    rs = np.random.RandomState(int(g["seed"]) + 1000)        # the generator's own stream (oracle/gen_golden.py)
+    random.seed(int(g["seed"]))
+    np.random.seed(int(g["seed"]))
+    env = gym_lmaze.make("lmaze-v6")
+    for t in range(len(g["ev_type"])):
+        ev, arg = int(g["ev_type"][t]), int(g["ev_arg"][t])
+        if ev == 0:
+            fov = env.reset()
+            assert obs_hash(fov) == g["fov_hash"][t], t
+        elif ev == 1:
+            # replicate the generator's choice between safeFovealGoal() and a random goal
+            rs_state = None
+            loc = None
+            # (the goal id recorded in the fixture tells which it was; safe goals consume np.random)
+            before = np.random.get_state()
+            sg = env.safeFovealGoal()
+            if sg != arg:
+                np.random.set_state(before)
+            loc = env.plannerStep(arg)
+            assert obs_hash(loc) == g["loc_hash"][t], t
+        else:
+            if g["raised"][t]:
+                with pytest.raises(IndexError):
+                    env.step(arg)
+            else:
+                out = env.step(arg)
+                assert len(out) == 8 and out[7] == arg and out[6].shape == (1, 5, 5)
+                assert obs_hash(out[0]) == g["fov_hash"][t] and obs_hash(out[1]) == g["loc_hash"][t], t
+                assert (out[2], out[3], out[4], out[5]) == (g["global_reward"][t], g["local_reward"][t],
+                                                            bool(g["global_done"][t]), bool(g["local_done"][t])), t
+                assert (out[6][0] == g["fgoal_plane"][t]).all()
+        assert (env.ball_x0, env.ball_y0) == tuple(g["ball0"][t]), t
+        assert (env.goal_x, env.goal_y) == tuple(g["goal"][t]), t

@@ -50,7 +50,7 @@ def test_validate_rejects_open_border_and_bad_cells():
 
 def test_registry_ids_and_entry_points():
     import gym_lmaze
-    assert gym_lmaze.registered_ids() == ["lmaze-v0", "lmaze-v1", "lmaze-v2", "lmaze-v3", "lmaze-v4"]
+    assert gym_lmaze.registered_ids() == ["lmaze-v%d" % k for k in range(7)]
     from gym_lmaze.envs import LmazeEnv, LmazeEnv_v3
     assert LmazeEnv.__name__ == "LmazeEnv" and LmazeEnv_v3.__name__ == "LmazeEnv_v3"
     with pytest.raises(KeyError):

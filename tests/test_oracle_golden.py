@@ -142,3 +142,50 @@ def test_oracle_v1_matches_reference(name):
         assert (st.obs[0].view(np.uint32) == g["planes"][t].view(np.uint32)).all(), t
         assert obs_hash(O.expand_planes(st.obs, E)[0]) == g["obs_hash"][t], t
     assert n_reset == len(g["reset_hash"])
+
+
+# ---------------------------------------------------------------------------------------
+# v5 / v6: event rollouts (reset / plannerStep / step), full state compared after every event
+# ---------------------------------------------------------------------------------------
+def check_v56_state(st, g, t, i=0):
+    assert tuple(st.ball_xy[i]) == tuple(g["ball0"][t]) and tuple(st.ball1_xy[i]) == tuple(g["ball1"][t]), t
+    assert tuple(st.goal_xy[i]) == tuple(g["goal"][t]) and tuple(st.fgoal_xy[i]) == tuple(g["fgoal"][t]), t
+    assert tuple(st.fovea_xy[i]) == tuple(g["fovea0"][t]) + tuple(g["fovea1"][t]), t
+    assert st.layout_id[i] == g["layout_id"][t], t
+    assert st.step_count[i] == g["step_count"][t] and st.foveal_step_count[i] == g["foveal_step_count"][t], t
+    assert f32_bits(st.reward)[i] == ref_reward_bits(g["global_reward"][t]), t
+    assert f32_bits(st.foveal_reward)[i] == ref_reward_bits(g["local_reward"][t]), t
+    assert st.done[i] == g["global_done"][t] and st.foveal_done[i] == g["local_done"][t], t
+    assert (st.visit[i].view(np.uint32) == g["visit"][t].view(np.uint32)).all(), t
+    plane = np.zeros(25, np.float32)
+    plane[st.foveal_goal[i]] = 1.0
+    assert (plane.reshape(5, 5) == g["fgoal_plane"][t]).all(), t
+
+
+@pytest.mark.parametrize("name", golden_files("v5_") + golden_files("v6_"))
+def test_oracle_v56_matches_reference(name):
+    g = load_golden(name)
+    layouts = np.ascontiguousarray(g["layouts"])
+    G, E = layouts.shape[-1], int(g["E"])
+    p = O.foveal_params(O.VARIANT_V5, G, layouts.shape[0])
+    st = O.FovealState(O.VARIANT_V5, 1, G)
+    for t in range(len(g["ev_type"])):
+        ev, arg = int(g["ev_type"][t]), int(g["ev_arg"][t])
+        if ev == 0:
+            st.ball_xy[0] = g["ball0"][t]
+            st.goal_xy[0] = g["goal"][t]
+            st.layout_id[0] = g["layout_id"][t]
+            O.v5_reset(p, layouts, None, 0, 0, 0, st)
+        elif ev == 1:
+            O.v5_planner_step(p, layouts, np.array([arg], np.int32), None, st)
+        else:
+            O.v5_step(p, layouts, np.array([arg], np.int32), st)
+        check_v56_state(st, g, t)
+        if g["raised"][t]:
+            continue            # the reference raised inside buildLocalObservation: no observation to compare
+        if ev in (0, 2):
+            assert (st.obs[0].view(np.uint32) == g["fov_planes"][t].view(np.uint32)).all(), t
+            assert obs_hash(O.expand_planes(st.obs, E)[0]) == g["fov_hash"][t], t
+        if ev in (1, 2):
+            assert (st.obs_local[0].view(np.uint32) == g["loc_planes"][t].view(np.uint32)).all(), t
+            assert obs_hash(O.expand_planes(st.obs_local, E)[0]) == g["loc_hash"][t], t
