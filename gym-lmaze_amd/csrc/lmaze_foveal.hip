@@ -31,7 +31,7 @@ struct FovealArgs {
     int64_t env_base;
 };
 
-struct EnvRec {           // what the render phase needs about one env
+struct EnvRec {           // one env after its transition (registers only; phase 1 turns it into plane masks)
     int16_t cx, cy;       // centre of the current window (ball after the move)
     int16_t px, py;       // centre of the "previous" window
     int16_t gx, gy;       // goal (v2/v4) or foveal goal (v1 local view)
@@ -45,7 +45,6 @@ struct EnvRec {           // what the render phase needs about one env
     int16_t upd;          // v5/v6: localDone -> this call halves the visit map (v5:313-318)
     int16_t pad;
 };
-static_assert(sizeof(EnvRec) == 40, "EnvRec layout");
 
 __device__ __forceinline__ float free_plane(uint8_t c) { return (c == 'B' || c == 'S' || c == 'X') ? 1.0f : 0.0f; }
 
@@ -69,31 +68,6 @@ __device__ __forceinline__ int count_or_kth(const uint8_t* lay, int G, int kind,
     return k < 0 ? cnt : -1;
 }
 
-// one observation element: channel ch, window cell (i, j) of env record r
-template <int VARIANT>
-__device__ __forceinline__ float obs_element(const EnvRec& r, const uint8_t* lays, const float* visit_tile, int G,
-                                             int ch, int i, int j) {
-    if (VARIANT == LMAZE_VARIANT_V1) {
-        const int x = r.cx - 2 + i, y = r.cy - 2 + j;
-        const bool in = x >= 0 && y >= 0 && x < G && y < G;
-        const uint8_t c = in ? lays[x * G + y] : (uint8_t)'W';
-        if (ch == 0) return (i == 2 && j == 2) ? 1.0f : 0.0f;                    // ball plane, v1:216
-        if (ch == 1) return (in && c == 'W') ? 1.0f : 0.0f;                      // wall, v1:70
-        if (ch == 2) return r.action ? ((in && x * G + y == r.flat) ? 1.0f : 0.0f)   // local goal, v1:244-245
-                                     : ((in && c == 'X') ? 1.0f : 0.0f);             // global goal, v1:74
-        return in ? free_plane(c) : 0.0f;                                        // free, v1:78
-    }
-    constexpr int PER = VARIANT == LMAZE_VARIANT_V2 ? 2 : 3;
-    if (ch == PER) return (r.action == i * FOV + j) ? 1.0f : 0.0f;               // action plane v2:135-136 / fovealGoal v5:166-169
-    const bool prev = ch > PER;
-    const int plane = prev ? ch - PER - 1 : ch;
-    const int x = (prev ? r.px : r.cx) - 2 + i, y = (prev ? r.py : r.cy) - 2 + j;
-    const bool in = x >= 0 && y >= 0 && x < G && y < G;
-    if (plane == 0) return in ? free_plane(lays[r.lid * G * G + x * G + y]) : 0.0f;   // v2:94
-    if (plane == 1) return (x == r.gx && y == r.gy) ? 1.0f : 0.0f;                    // v2:95
-    return in ? visit_tile[x * G + y] : 0.0f;                                         // v4 visit map (live view)
-}
-
 // numpy index semantics on an axis of 5: -5..-1 wrap, anything else outside 0..4 raises (-> -1)
 __device__ __forceinline__ int wrap5(int i) {
     if (i >= 0 && i < FOV) return i;
@@ -101,17 +75,25 @@ __device__ __forceinline__ int wrap5(int i) {
     return -1;
 }
 
-// v5 buildLocalObservation (v5:356-380): free window at fovea_0, ball and previous ball relative to
-// fovea_1, fovealGoal plane
-__device__ __forceinline__ float loc_element(const EnvRec& r, const uint8_t* lays, int G, int ch, int i, int j) {
-    if (ch == 0) {
-        const int x = r.cx - 2 + i, y = r.cy - 2 + j;
-        const bool in = x >= 0 && y >= 0 && x < G && y < G;
-        return in ? free_plane(lays[r.lid * G * G + x * G + y]) : 0.0f;
+// 25-bit mask (bit 5*i+j) of a 5x5 window centred on (cx, cy) over a plane given as one 64-bit row
+// mask per layout row (bit y = cell (x, y) is set); cells outside the array read 0
+__device__ __forceinline__ uint32_t window_bits(const uint64_t* rows, int G, int cx, int cy) {
+    uint32_t m = 0;
+    const int y0 = cy - 2;
+#pragma unroll
+    for (int i = 0; i < FOV; ++i) {
+        const int x = cx - 2 + i;
+        const uint64_t b = (x >= 0 && x < G) ? rows[x] : 0ull;
+        const uint32_t w = (uint32_t)(y0 >= 0 ? (b >> y0) : (b << -y0)) & 31u;
+        m |= w << (FOV * i);
     }
-    if (ch == 3) return (r.action == i * FOV + j) ? 1.0f : 0.0f;
-    const int bi = wrap5((ch == 1 ? r.b0x : r.b1x) - r.f1x + 2), bj = wrap5((ch == 1 ? r.b0y : r.b1y) - r.f1y + 2);
-    return (bi == i && bj == j) ? 1.0f : 0.0f;
+    return m;
+}
+
+// bit of cell (tx, ty) inside the window centred on (cx, cy), 0 if it is outside the window
+__device__ __forceinline__ uint32_t onehot_bits(int tx, int ty, int cx, int cy) {
+    const int i = tx - cx + 2, j = ty - cy + 2;
+    return (i >= 0 && i < FOV && j >= 0 && j < FOV) ? (1u << (FOV * i + j)) : 0u;
 }
 
 template <int VARIANT, int MODE, int EPB>
@@ -122,10 +104,18 @@ __global__ __launch_bounds__(LMAZE_BLOCK) void foveal_kernel(const FovealArgs a)
     constexpr int PERENV = C * W25;  // floats of observation per env
     const int G = a.p.grid, CELLS = G * G, L = V1 ? 1 : a.p.n_layouts;
 
+    // LDS: per-env plane masks and window centres, the two 5x5 samples of the visit map (v4-v6), one
+    // 64-bit row mask per layout row for each static plane, and the layout characters for the transition
     extern __shared__ int4 lds4[];
-    EnvRec* rec = reinterpret_cast<EnvRec*>(lds4);                         // [EPB]
-    float* vtile = reinterpret_cast<float*>(rec + EPB);                    // [EPB*CELLS] (v4 only)
-    uint8_t* lays = reinterpret_cast<uint8_t*>(vtile + (V4 ? EPB * CELLS : 0));  // [L*CELLS]
+    uint32_t* masks = reinterpret_cast<uint32_t*>(lds4);                   // [EPB][8]  25-bit planes of obs
+    uint32_t* lmasks = masks + EPB * 8;                                    // [EPB][4]  planes of obs_local (v5/v6)
+    int16_t* cen = reinterpret_cast<int16_t*>(lmasks + EPB * 4);           // [EPB][4]  cx, cy, px, py
+    int32_t* flags = reinterpret_cast<int32_t*>(cen + EPB * 4);            // [EPB]     bit0 skip, bit1 visit update
+    float* vwin = reinterpret_cast<float*>(flags + EPB);                   // [EPB][2][25] visit-map samples (v4-v6)
+    uint64_t* rowfree = reinterpret_cast<uint64_t*>(vwin + (V4 ? EPB * 2 * W25 : 0));  // [L*G] free = B|S|X
+    uint64_t* rowwall = rowfree + L * G;                                   // [G] v1: 'W'
+    uint64_t* rowx = rowwall + G;                                          // [G] v1: 'X'
+    uint8_t* lays = reinterpret_cast<uint8_t*>(rowx + G);                  // [L*CELLS]
     __shared__ int any_skip;
 
     const int tid = threadIdx.x;
@@ -133,6 +123,18 @@ __global__ __launch_bounds__(LMAZE_BLOCK) void foveal_kernel(const FovealArgs a)
     const int nb = (int)min((int64_t)EPB, a.n - blockbase);
     if (tid == 0) any_skip = 0;
     for (int i = tid; i < L * CELLS; i += LMAZE_BLOCK) lays[i] = a.layouts[i];
+    __syncthreads();
+    for (int i = tid; i < L * G; i += LMAZE_BLOCK) {
+        uint64_t fr = 0, wl = 0, xx = 0;
+        for (int y = 0; y < G; ++y) {
+            const uint8_t c = lays[i * G + y];
+            fr |= (uint64_t)(c == 'B' || c == 'S' || c == 'X') << y;       // v1:78, v2:94
+            wl |= (uint64_t)(c == 'W') << y;                                // v1:70
+            xx |= (uint64_t)(c == 'X') << y;                                // v1:74
+        }
+        rowfree[i] = fr;
+        if (V1) { rowwall[i] = wl; rowx[i] = xx; }
+    }
     __syncthreads();
 
     // ---------------- phase 1: one lane per env ----------------
@@ -366,71 +368,125 @@ __global__ __launch_bounds__(LMAZE_BLOCK) void foveal_kernel(const FovealArgs a)
             r.gx = (int16_t)gx; r.gy = (int16_t)gy;
         }
         r.cx = (int16_t)bx; r.cy = (int16_t)by;
-        rec[le] = r;
+        // the observation as 25-bit planes (the float visit planes are sampled in phase 3)
+        uint32_t* m = masks + le * 8;
+        if (V1) {
+            m[0] = 1u << 12;                                                               // ball, v1:216
+            m[1] = window_bits(rowwall, G, r.cx, r.cy);
+            m[2] = r.action ? (r.flat >= 0 ? onehot_bits(r.flat / G, r.flat % G, r.cx, r.cy) : 0u)   // v1:244-245
+                            : window_bits(rowx, G, r.cx, r.cy);
+            m[3] = window_bits(rowfree, G, r.cx, r.cy);
+        } else {
+            constexpr int PER = VARIANT == LMAZE_VARIANT_V2 ? 2 : 3;
+            const uint64_t* rows = rowfree + r.lid * G;
+            m[0] = window_bits(rows, G, r.cx, r.cy);                                       // v2:94
+            m[1] = onehot_bits(r.gx, r.gy, r.cx, r.cy);                                    // v2:95
+            m[PER] = (r.action >= 0 && r.action < W25) ? (1u << r.action) : 0u;            // v2:135-136, v5:166-169
+            m[PER + 1] = window_bits(rows, G, r.px, r.py);
+            m[PER + 2] = onehot_bits(r.gx, r.gy, r.px, r.py);
+            if (V5) {                                                                      // v5:356-380
+                uint32_t* lm = lmasks + le * 4;
+                lm[0] = m[0];
+                const int i0 = wrap5(r.b0x - r.f1x + 2), j0 = wrap5(r.b0y - r.f1y + 2);
+                const int i1 = wrap5(r.b1x - r.f1x + 2), j1 = wrap5(r.b1y - r.f1y + 2);
+                lm[1] = (i0 >= 0 && j0 >= 0) ? (1u << (FOV * i0 + j0)) : 0u;
+                lm[2] = (i1 >= 0 && j1 >= 0) ? (1u << (FOV * i1 + j1)) : 0u;
+                lm[3] = m[PER];
+            }
+        }
+        cen[le * 4 + 0] = r.cx; cen[le * 4 + 1] = r.cy; cen[le * 4 + 2] = r.px; cen[le * 4 + 3] = r.py;
+        flags[le] = (r.skip ? 1 : 0) | (r.upd ? 2 : 0);
         if (r.skip) any_skip = 1;
     }
     __syncthreads();
     const bool some_skipped = any_skip != 0;
 
-    // ---------------- phase 2 (v4): stream the visit maps, v4:116-119 / v4:211-214 ----------------
+    // ---------------- phase 2 (v4-v6): the visit maps, v4:116-119 / v4:211-214 / v5:313-318 ----------------
+    // Envs whose map changes are streamed through (load, + window, halve, store; 16-byte accesses) and
+    // the cells that fall in their two observation windows are kept in LDS on the way; envs whose map
+    // does not change (v5/v6 without localDone) only have those 2 x 25 cells gathered.
     if (V4 && !(V5 && MODE == FM_PLANNER)) {
         float* vis = a.b.visit + (size_t)blockbase * CELLS;
         const int total = nb * CELLS;
+        auto keep = [&](int le, int c, float v) {   // c = cell index of env le; stash it if a window shows it
+            const int x = c / G, y = c - x * G;
+            int i = x - cen[le * 4] + 2, j = y - cen[le * 4 + 1] + 2;
+            if (i >= 0 && i < FOV && j >= 0 && j < FOV) vwin[le * 2 * W25 + i * FOV + j] = v;
+            i = x - cen[le * 4 + 2] + 2; j = y - cen[le * 4 + 3] + 2;
+            if (i >= 0 && i < FOV && j >= 0 && j < FOV) vwin[le * 2 * W25 + W25 + i * FOV + j] = v;
+        };
+        auto update = [&](float v, int c, int cx, int cy) -> float {
+            const int x = c / G, y = c - x * G;
+            const float w = (x >= cx - 2 && x <= cx + 2 && y >= cy - 2 && y <= cy + 2) ? 1.0f : 0.0f;
+            return (v + w) * 0.5f;  // float32 add + exact halving == the reference's float64 round trip
+        };
+        // window cells outside the array read 0 (the padded layouts never get there)
+        for (int i = tid; i < nb * 2 * W25; i += LMAZE_BLOCK) vwin[i] = 0.0f;
+        __syncthreads();
         if ((CELLS & 3) == 0) {  // a 16-byte access never straddles two envs
             for (int q = tid; q < (total >> 2); q += LMAZE_BLOCK) {
                 const int f0 = q << 2;
                 const int le = f0 / CELLS;
-                const EnvRec r = rec[le];
                 const int c0 = f0 - le * CELLS;
-                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (r.skip || MODE == FM_STEP) v = reinterpret_cast<const float4*>(vis)[q];
-                if (V5 && !r.skip && MODE == FM_RESET) {
-                    reinterpret_cast<float4*>(vis)[q] = v;             // v5:130: zeroed, no window added at reset
-                } else if (!r.skip && (!V5 || r.upd)) {
-                    float* pv = reinterpret_cast<float*>(&v);
-#pragma unroll
-                    for (int k = 0; k < 4; ++k) {
-                        const int x = (c0 + k) / G, y = (c0 + k) - x * G;
-                        const float w = (x >= r.cx - 2 && x <= r.cx + 2 && y >= r.cy - 2 && y <= r.cy + 2) ? 1.0f : 0.0f;
-                        pv[k] = (pv[k] + w) * 0.5f;  // float32 add + exact halving == the reference's float64 round trip
-                    }
-                    reinterpret_cast<float4*>(vis)[q] = v;
+                const int fl = flags[le];
+                const bool skip = fl & 1, upd = fl & 2;
+                if (skip || (V5 && MODE == FM_STEP && !upd)) continue;      // map unchanged: gathered below
+                const int cx = cen[le * 4], cy = cen[le * 4 + 1];
+                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);                 // reset: v4:112 / v5:130
+                if (MODE == FM_STEP) v = reinterpret_cast<const float4*>(vis)[q];
+                if (!(V5 && MODE == FM_RESET)) {                            // v5 adds no window at reset
+                    v.x = update(v.x, c0, cx, cy);
+                    v.y = update(v.y, c0 + 1, cx, cy);
+                    v.z = update(v.z, c0 + 2, cx, cy);
+                    v.w = update(v.w, c0 + 3, cx, cy);
                 }
-                reinterpret_cast<float4*>(vtile)[q] = v;
+                reinterpret_cast<float4*>(vis)[q] = v;
+                keep(le, c0, v.x); keep(le, c0 + 1, v.y); keep(le, c0 + 2, v.z); keep(le, c0 + 3, v.w);
             }
         } else {
             for (int f = tid; f < total; f += LMAZE_BLOCK) {
                 const int le = f / CELLS;
-                const EnvRec r = rec[le];
                 const int c = f - le * CELLS;
-                float v = (r.skip || MODE == FM_STEP) ? vis[f] : 0.0f;
-                if (V5 && !r.skip && MODE == FM_RESET) {
-                    vis[f] = v;
-                } else if (!r.skip && (!V5 || r.upd)) {
-                    const int x = c / G, y = c - x * G;
-                    const float w = (x >= r.cx - 2 && x <= r.cx + 2 && y >= r.cy - 2 && y <= r.cy + 2) ? 1.0f : 0.0f;
-                    v = (v + w) * 0.5f;
-                    vis[f] = v;
-                }
-                vtile[f] = v;
+                const int fl = flags[le];
+                const bool skip = fl & 1, upd = fl & 2;
+                if (skip || (V5 && MODE == FM_STEP && !upd)) continue;
+                float v = MODE == FM_STEP ? vis[f] : 0.0f;
+                if (!(V5 && MODE == FM_RESET)) v = update(v, c, cen[le * 4], cen[le * 4 + 1]);
+                vis[f] = v;
+                keep(le, c, v);
+            }
+        }
+        if (V5 && MODE == FM_STEP) {  // unchanged maps: gather the two windows straight from HBM
+            for (int i = tid; i < nb * 2 * W25; i += LMAZE_BLOCK) {
+                const int le = i / (2 * W25);
+                if (flags[le] & 3) continue;
+                const int r = i - le * 2 * W25;
+                const int w = r / W25, cell = r - w * W25;
+                const int x = cen[le * 4 + 2 * w] - 2 + cell / FOV, y = cen[le * 4 + 2 * w + 1] - 2 + cell % FOV;
+                if (x >= 0 && y >= 0 && x < G && y < G) vwin[i] = vis[le * CELLS + x * G + y];
             }
         }
         __syncthreads();
     }
 
     // ---------------- phase 3: render float[nb*C*25], contiguous, 16-byte stores ----------------
+    auto element = [&](int le, int rem) -> float {
+        const int ch = rem / W25, cell = rem - ch * W25;
+        if (V4 && (ch == 2 || ch == 6))   // visit map, sampled live at the current / "previous" window
+            return vwin[le * 2 * W25 + (ch == 2 ? 0 : W25) + cell];
+        return ((masks[le * 8 + ch] >> cell) & 1u) ? 1.0f : 0.0f;
+    };
     float* obs = a.b.obs + (size_t)blockbase * PERENV;
     const int R = (V5 && MODE == FM_PLANNER) ? 0 : nb * PERENV;   // plannerStep returns only the local observation
     const int nq = some_skipped ? 0 : (R >> 2);
     for (int q = tid; q < nq; q += LMAZE_BLOCK) {
-        int f = q << 2;
+        const int f = q << 2;
         int le = f / PERENV;
         int rem = f - le * PERENV;
         float v[4];
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
-            const int ch = rem / W25, cell = rem - ch * W25;
-            v[k] = obs_element<VARIANT>(rec[le], lays, vtile + le * CELLS, G, ch, cell / FOV, cell % FOV);
+            v[k] = element(le, rem);
             if (++rem == PERENV) { rem = 0; ++le; }
         }
         reinterpret_cast<float4*>(obs)[q] = make_float4(v[0], v[1], v[2], v[3]);
@@ -438,10 +494,8 @@ __global__ __launch_bounds__(LMAZE_BLOCK) void foveal_kernel(const FovealArgs a)
     // scalar path: the ragged tail, or every element when some env of the workgroup is skipped
     for (int f = (nq << 2) + tid; f < R; f += LMAZE_BLOCK) {
         const int le = f / PERENV;
-        if (rec[le].skip) continue;
-        const int rem = f - le * PERENV;
-        const int ch = rem / W25, cell = rem - ch * W25;
-        obs[f] = obs_element<VARIANT>(rec[le], lays, vtile + le * CELLS, G, ch, cell / FOV, cell % FOV);
+        if (flags[le] & 1) continue;
+        obs[f] = element(le, f - le * PERENV);
     }
 
     // ---------------- phase 3b (v5/v6): the local observation float[nb*4*25], v5:356-380 ----------------
@@ -452,13 +506,13 @@ __global__ __launch_bounds__(LMAZE_BLOCK) void foveal_kernel(const FovealArgs a)
         for (int q = tid; q < (RL >> 2); q += LMAZE_BLOCK) {
             const int f = q << 2;
             const int le = f / PERLOC;
-            if (rec[le].skip) continue;
+            if (flags[le] & 1) continue;
             const int rem = f - le * PERLOC;
             float v[4];
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
                 const int ch = (rem + k) / W25, cell = (rem + k) - ch * W25;
-                v[k] = loc_element(rec[le], lays, G, ch, cell / FOV, cell % FOV);
+                v[k] = ((lmasks[le * 4 + ch] >> cell) & 1u) ? 1.0f : 0.0f;
             }
             reinterpret_cast<float4*>(loc)[q] = make_float4(v[0], v[1], v[2], v[3]);
         }
@@ -557,8 +611,9 @@ template <int VARIANT, int MODE, int EPB>
 static hipError_t launch_foveal_one(const FovealArgs& a, hipStream_t s) {
     const int cells = a.p.grid * a.p.grid;
     const int L = VARIANT == LMAZE_VARIANT_V1 ? 1 : a.p.n_layouts;
-    size_t lds = sizeof(EnvRec) * EPB + (size_t)((L * cells + 15) & ~15);
-    if (VARIANT == LMAZE_VARIANT_V4 || VARIANT == LMAZE_VARIANT_V5) lds += (size_t)EPB * cells * 4;
+    // masks 32 B + lmasks 16 B + centres 8 B + flags 4 B per env, row masks, layout characters, visit samples
+    size_t lds = (size_t)EPB * 60 + ((size_t)L * a.p.grid + 2 * (size_t)a.p.grid) * 8 + (size_t)((L * cells + 15) & ~15);
+    if (VARIANT == LMAZE_VARIANT_V4 || VARIANT == LMAZE_VARIANT_V5) lds += (size_t)EPB * 2 * W25 * 4;
     const int64_t blocks = (a.n + EPB - 1) / EPB;
     hipLaunchKernelGGL((foveal_kernel<VARIANT, MODE, EPB>), dim3((unsigned)blocks), dim3(LMAZE_BLOCK), lds, s, a);
     return hipGetLastError();
@@ -572,12 +627,10 @@ static hipError_t launch_foveal_mode(const FovealArgs& a, hipStream_t s) {
         case LMAZE_VARIANT_V2: return launch_foveal_one<LMAZE_VARIANT_V2, MODE, 256>(a, s);
         case LMAZE_VARIANT_V5:
         case LMAZE_VARIANT_V6:
-            if (a.p.grid * a.p.grid * 4 * 32 <= 96 * 1024) return launch_foveal_one<LMAZE_VARIANT_V5, MODE, 32>(a, s);
-            return launch_foveal_one<LMAZE_VARIANT_V5, MODE, 8>(a, s);
+            return launch_foveal_one<LMAZE_VARIANT_V5, MODE, 64>(a, s);
         default:
-            // v4 tiles the workgroup's visit maps in LDS: 32 envs of 18x18 floats = 41 KiB
-            if (a.p.grid * a.p.grid * 4 * 32 <= 96 * 1024) return launch_foveal_one<LMAZE_VARIANT_V4, MODE, 32>(a, s);
-            return launch_foveal_one<LMAZE_VARIANT_V4, MODE, 8>(a, s);
+            // 64 envs per workgroup: 83 KiB of visit maps streamed + 45 KiB of observation written
+            return launch_foveal_one<LMAZE_VARIANT_V4, MODE, 64>(a, s);
     }
 }
 
