@@ -84,20 +84,12 @@ __device__ __forceinline__ void decode_action(int a, int& ox, int& oy) {
 
 __device__ __forceinline__ int clampi(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
 
-// One env's transition.  `lay` is that env's layout (LDS).  Returns the new ball cell index.
-// Out-of-range coordinates cannot occur with a 'W'-bordered layout (the reference would
-// raise IndexError or wrap); indices are clamped only so a bad input cannot fault the GPU.
+// The transition rule itself, on values: c = character of the target cell (bx+ox, by+oy).
+// Returns true when v0 counts a goal hit (v0:195).
 template <int VARIANT>
-__device__ __forceinline__ void transition(const StepArgs& a, const uint8_t* lay, int G, int64_t e,
-                                           int sc_in, float r_in, int& bx, int& by, int gx, int gy) {
-    const int act = a.action[e];
-    const int sc = sc_in + 1;  // v0:151, v3:225
-    int ox, oy;
-    decode_action(act, ox, oy);
-    const int tx = clampi(bx + ox, 0, G - 1), ty = clampi(by + oy, 0, G - 1);
-    const uint8_t c = lay[tx * G + ty];  // v0:172, v3:251
-    float r;
-    bool dn;
+__device__ __forceinline__ bool transition_rule(const StepArgs& a, uint8_t c, int ox, int oy, int tx, int ty, int sc,
+                                                float r_in, int gx, int gy, int& bx, int& by, float& r, bool& dn) {
+    bool hit = false;
     if (VARIANT == LMAZE_VARIANT_V3) {
         r = -0.0f;  // v3:224
         if (c == 'W') {
@@ -117,10 +109,29 @@ __device__ __forceinline__ void transition(const StepArgs& a, const uint8_t* lay
         } else if (c == 'X') {
             bx = tx; by = ty;   // v0:190-191
             r = a.reward_goal;  // v0:194
-            if (a.goal_count) a.goal_count[e] += 1;  // v0:195
+            hit = true;         // v0:195
         }
         dn = (r == a.reward_goal) || (sc == a.step_limit);  // v0:246-249
     }
+    return hit;
+}
+
+// One env's transition against `lay`, that env's layout (LDS), with the SoA loads/stores.
+// Out-of-range coordinates cannot occur with a 'W'-bordered layout (the reference would
+// raise IndexError or wrap); indices are clamped only so a bad input cannot fault the GPU.
+template <int VARIANT>
+__device__ __forceinline__ void transition(const StepArgs& a, const uint8_t* lay, int G, int64_t e,
+                                           int sc_in, float r_in, int& bx, int& by, int gx, int gy) {
+    const int act = a.action[e];
+    const int sc = sc_in + 1;  // v0:151, v3:225
+    int ox, oy;
+    decode_action(act, ox, oy);
+    const int tx = clampi(bx + ox, 0, G - 1), ty = clampi(by + oy, 0, G - 1);
+    const uint8_t c = lay[tx * G + ty];  // v0:172, v3:251
+    float r;
+    bool dn;
+    if (transition_rule<VARIANT>(a, c, ox, oy, tx, ty, sc, r_in, gx, gy, bx, by, r, dn) && a.goal_count)
+        a.goal_count[e] += 1;
     a.ball[e] = make_int2(bx, by);
     a.step_count[e] = sc;
     a.reward[e] = r;

@@ -332,8 +332,107 @@ __global__ __launch_bounds__(LMAZE_BLOCK) void step_perenv_kernel(const StepArgs
 }
 
 // ------------------------------------------------------------------------------------
+// Per-env layouts, register-tiled: one WAVE per env, no LDS, no barrier (G*G a multiple of
+// 256: G = 16, 32, 48, 64).  Lane l loads dword 64*j + l of the env's layout (256 B per wave
+// instruction, each byte read from HBM once) and keeps it in registers; the target cell of
+// the transition is fetched with v_readlane; every quantity of the transition is
+// wave-uniform, lane 0 stores it; the lane's 4 cells per register become one 16-byte store,
+// so every wave store instruction writes 1 KiB contiguous.  Waves never wait for each other.
+// ------------------------------------------------------------------------------------
+template <int G, int VARIANT, bool DO_STEP, bool NT>
+__global__ __launch_bounds__(LMAZE_BLOCK) void step_perenv_wave_kernel(const StepArgs a) {
+    constexpr bool V3 = VARIANT == LMAZE_VARIANT_V3;
+    constexpr int CELLS = G * G, NJ = CELLS / 256;
+    static_assert(CELLS % 256 == 0, "whole dwords per lane");
+    const int lane = threadIdx.x & 63;
+    const int EPW = a.envs_per_block;  // envs per wave
+    const int64_t wave = (int64_t)blockIdx.x * (LMAZE_BLOCK / 64) + (threadIdx.x >> 6);
+    const bool autoreset = DO_STEP && a.auto_reset;
+    const bool masked = !DO_STEP && a.mask != nullptr;
+
+#pragma unroll 1
+    for (int k = 0; k < EPW; ++k) {
+        const int64_t e = wave * EPW + k;
+        if (e >= a.n) break;
+        if (masked && !a.mask[e]) continue;
+        const uint32_t* lay32 = reinterpret_cast<const uint32_t*>(a.layout + (size_t)e * CELLS);
+        uint32_t w[NJ];
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) w[j] = lay32[j * 64 + lane];
+
+        int2 b = a.ball[e];
+        int2 g = make_int2(-1, -1);
+        if (V3) g = a.goal[e];
+        if (DO_STEP) {
+            const int act = a.action[e];
+            int sc_in = a.step_count[e];
+            float r_in = V3 ? 0.0f : a.reward[e];
+            if (autoreset && a.done[e]) {  // rare: re-place with ballot scans of the layout (L2-hot)
+                int bc, gc;
+                wave_place<VARIANT>(a.layout + (size_t)e * CELLS, G, CELLS, env_draw(a.seed, a.epoch, a.env_base + e), lane,
+                                    bc, gc);
+                if (bc >= 0) b = make_int2(bc / G, bc % G);
+                if (V3 && gc >= 0) {
+                    g = make_int2(gc / G, gc % G);
+                    if (lane == 0) a.goal_rw[e] = g;
+                }
+                sc_in = 0;
+                r_in = -0.0f;
+            }
+            int bx = clampi(b.x, 0, G - 1), by = clampi(b.y, 0, G - 1);
+            int ox, oy;
+            decode_action(act, ox, oy);
+            const int tx = clampi(bx + ox, 0, G - 1), ty = clampi(by + oy, 0, G - 1);
+            const int t = __builtin_amdgcn_readfirstlane(tx * G + ty);  // wave-uniform by construction
+            const int tw = t >> 2;                                      // dword of the layout holding the target cell
+            uint32_t word = 0;
+#pragma unroll
+            for (int j = 0; j < NJ; ++j)
+                if ((tw >> 6) == j) word = __builtin_amdgcn_readlane(w[j], tw & 63);
+            const uint8_t c = (uint8_t)(word >> (8 * (t & 3)));
+            float r;
+            bool dn;
+            const int sc = sc_in + 1;
+            const bool hit = transition_rule<VARIANT>(a, c, ox, oy, tx, ty, sc, r_in, g.x, g.y, bx, by, r, dn);
+            if (lane == 0) {
+                if (hit && a.goal_count) a.goal_count[e] += 1;
+                a.ball[e] = make_int2(bx, by);
+                a.step_count[e] = sc;
+                a.reward[e] = r;
+                a.done[e] = dn ? 1 : 0;
+            }
+            b = make_int2(bx, by);
+        } else {
+            b = make_int2(clampi(b.x, 0, G - 1), clampi(b.y, 0, G - 1));
+        }
+        if (a.obs == nullptr) continue;
+        const int bcell = b.x * G + b.y;
+        const int gcell = (V3 && g.x >= 0 && g.x < G && g.y >= 0 && g.y < G) ? g.x * G + g.y : -8;
+        int4* obs4 = reinterpret_cast<int4*>(a.obs + (size_t)e * CELLS);
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+            const int c0 = (j * 64 + lane) << 2;  // first of this lane's 4 cells
+            int vals[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                int v = cell_bits<VARIANT>((uint8_t)(w[j] >> (8 * q)));
+                v |= (bcell == c0 + q) ? LMAZE_OBS_BALL : 0;
+                if (V3) v |= (gcell == c0 + q) ? LMAZE_OBS_GOAL : 0;
+                vals[q] = v;
+            }
+            store16<NT>(obs4 + j * 64 + lane, make_int4(vals[0], vals[1], vals[2], vals[3]));
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------
 // host launchers
 // ------------------------------------------------------------------------------------
+// Obs buffers larger than this are written with non-temporal stores: they cannot stay in the
+// 256 MiB Infinity Cache anyway, and streaming them past L2 measured 0-7 % faster on MI355X;
+// smaller buffers keep plain stores so the consumer of the observation finds them on-die.
+static const size_t kNonTemporalObsBytes = (size_t)192 << 20;
+
 static size_t shared_lds_bytes(int G, bool specialised, int epb) {
     const int cells = G * G;
     const int pat = (specialised && (G & 1)) ? 4 * cells : cells;
@@ -353,10 +452,6 @@ static size_t perenv_lds_bytes(int G, int epb) {
     return (size_t)((epb * G * G + 15) & ~15) + (3 * (size_t)(epb + 1) + 2 * (size_t)epb) * 4;
 }
 
-// Obs buffers larger than this are written with non-temporal stores: they cannot stay in the
-// 256 MiB Infinity Cache anyway, and streaming them past L2 measured 0-7 % faster on MI355X;
-// smaller buffers keep plain stores so the consumer of the observation finds them on-die.
-static const size_t kNonTemporalObsBytes = (size_t)192 << 20;
 
 // LDS bytes that make exactly `k` workgroups fit a CU's 160 KiB (midway between the k and
 // k+1 thresholds, clear of the allocation granule).
@@ -395,8 +490,34 @@ static hipError_t launch_shared(const StepArgs& a, hipStream_t s) {
     return hipGetLastError();
 }
 
+template <int G, int VARIANT, bool DO_STEP>
+static hipError_t launch_perenv_wave(const StepArgs& a, hipStream_t s) {
+    // One env per wave measured best at 1M x 32x32 (bench.py --workload c5): 0.873 ms per step
+    // (0.775 of HBM peak, non-temporal stores) against 0.985 ms with four envs per wave and 0.96 ms
+    // for the LDS-tiled kernel -- short-lived waves, as with the one-store-per-thread fill.
+    StepArgs b = a;
+    b.envs_per_block = 1;
+    const int64_t per_block = (int64_t)b.envs_per_block * (LMAZE_BLOCK / 64);
+    const int64_t blocks = (a.n + per_block - 1) / per_block;
+    const bool nt = a.obs != nullptr && (size_t)a.n * G * G * 4 > kNonTemporalObsBytes;
+    if (nt)
+        hipLaunchKernelGGL((step_perenv_wave_kernel<G, VARIANT, DO_STEP, true>), dim3((unsigned)blocks),
+                           dim3(LMAZE_BLOCK), 0, s, b);
+    else
+        hipLaunchKernelGGL((step_perenv_wave_kernel<G, VARIANT, DO_STEP, false>), dim3((unsigned)blocks),
+                           dim3(LMAZE_BLOCK), 0, s, b);
+    return hipGetLastError();
+}
+
 template <int GT, int VARIANT, bool DO_STEP>
 static hipError_t launch_perenv(const StepArgs& a, hipStream_t s) {
+    // G*G a multiple of 256: the register-tiled one-wave-per-env kernel
+    if constexpr (GT == 32) return launch_perenv_wave<32, VARIANT, DO_STEP>(a, s);
+    if constexpr (GT == 0) {
+        if (a.grid == 16) return launch_perenv_wave<16, VARIANT, DO_STEP>(a, s);
+        if (a.grid == 48) return launch_perenv_wave<48, VARIANT, DO_STEP>(a, s);
+        if (a.grid == 64) return launch_perenv_wave<64, VARIANT, DO_STEP>(a, s);
+    }
     StepArgs b = a;
     b.envs_per_block = perenv_envs_per_block(a.grid);
     const int64_t blocks = (a.n + b.envs_per_block - 1) / b.envs_per_block;

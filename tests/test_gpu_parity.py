@@ -214,7 +214,7 @@ def test_shared_layout_generic_grids(variant, G):
     _compare_rollout(variant, 1030 if G < 40 else 300, G, 24, shared=True, seed=G)
 
 
-@pytest.mark.parametrize("G", [8, 11, 12, 32, 7, 9, 21, 40])
+@pytest.mark.parametrize("G", [8, 11, 12, 32, 7, 9, 21, 40, 16, 48, 64])
 @pytest.mark.parametrize("variant", ["v0", "v3"])
 def test_per_env_layouts(variant, G):
     _compare_rollout(variant, 1537 if G < 40 else 200, G, 24, shared=False, seed=G + 7)
