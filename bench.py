@@ -110,10 +110,23 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     dist = None
-    if world > 1:
+    if world > 1 or "RANK" in os.environ:      # launched by torch.distributed.run (also with one rank)
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        os.environ.setdefault("MASTER_PORT", "29511")
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
+        # RCCL prints a banner on fd 1 when it loads; keep stdout for the ONE JSON line
+        sys.stdout.flush()
+        saved = os.dup(1)
+        os.dup2(2, 1)
+        try:
+            dist.init_process_group("nccl", device_id=dev)   # "nccl" is RCCL on ROCm; barrier + one MAX only
+            dist.barrier()
+        finally:
+            sys.stdout.flush()
+            os.dup2(saved, 1)
+            os.close(saved)
 
     pkg = importlib.import_module("gym-lmaze_amd")
     G, N = args.grid, args.envs
@@ -177,9 +190,7 @@ def main():
         elapsed = time.perf_counter() - t0
         if dist is not None:
             dist.barrier()
-            tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-            elapsed = float(tt.item())
+            elapsed = pkg.max_over_ranks(elapsed, device=dev)
     # per-launch GPU time from HIP events recorded on the launch stream
     kern_ms = float(ev0.elapsed_time(ev1) / args.steps)   # ms per launch, launch gaps included
 
@@ -220,7 +231,7 @@ def main():
                          "kernel": "lmaze::step_%s_kernel<%d, v0>" % ("perenv" if args.per_env_layouts else "shared", G),
                          "bytes_per_env_step": B, "kernel_ms_avg": kern_ms},
         }
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:      # rank 0 at N=1 only
             out["cpu_baseline"] = cpu_baseline(G, layout)
         print(json.dumps(out))
     if dist is not None:

@@ -14,3 +14,27 @@ def shard_range(num_envs_total, rank, world_size):
     start = rank * base + min(rank, rem)
     count = base + (1 if rank < rem else 0)
     return start, count
+
+
+def max_over_ranks(value, device=None):
+    """MAX of a per-rank scalar over the process group (the elapsed time of a timed region): the only
+    reduction the multi-GPU bench needs.  No process group (single process) -> the value itself.
+    Works on any backend: nccl (= RCCL) with a device tensor, gloo on the CPU."""
+    import torch
+    import torch.distributed as dist
+    if not (dist.is_available() and dist.is_initialized()):
+        return float(value)
+    t = torch.tensor([float(value)], dtype=torch.float64, device=device if device is not None else "cpu")
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return float(t.item())
+
+
+def sum_over_ranks(values, device=None):
+    """SUM of a small vector of per-rank counters (episode statistics): off the step
+    path, a handful of scalars per call."""
+    import torch
+    import torch.distributed as dist
+    t = torch.as_tensor(values, dtype=torch.int64, device=device if device is not None else "cpu").clone()
+    if dist.is_available() and dist.is_initialized():
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+    return t

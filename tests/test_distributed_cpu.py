@@ -85,3 +85,22 @@ def test_two_rank_shards_equal_single_process(tmp_path):
         assert (d["rew"].view(np.uint32) == rew[s:s + c].view(np.uint32)).all()
         seen += c
     assert seen == total
+
+
+def _reduce_worker(rank, world, port):
+    sys.path.insert(0, ROOT)
+    S = importlib.import_module("gym-lmaze_amd.sharding")
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    assert S.max_over_ranks(10.0 + rank) == 10.0 + world - 1
+    tot = S.sum_over_ranks([rank + 1, 5, 100 * rank])
+    assert tot.tolist() == [sum(r + 1 for r in range(world)), 5 * world, sum(100 * r for r in range(world))]
+    dist.destroy_process_group()
+
+
+def test_bench_reductions_world2():
+    """the two reductions the multi-GPU bench / episode statistics use, over gloo with 2 ranks"""
+    S = importlib.import_module("gym-lmaze_amd.sharding")
+    assert S.max_over_ranks(3.5) == 3.5 and S.sum_over_ranks([1, 2]).tolist() == [1, 2]   # no process group
+    mp.spawn(_reduce_worker, args=(2, _free_port()), nprocs=2, join=True)
