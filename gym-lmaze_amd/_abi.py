@@ -22,7 +22,7 @@ MAX_GRID, MAX_CHANNELS = 64, 8
 # checks this list and the loaded library against it)
 SYMBOLS = ("lmaze_abi_version", "lmaze_strerror", "lmaze_device_info", "lmaze_step_v0", "lmaze_step_v3",
            "lmaze_step_v0_autoreset", "lmaze_step_v3_autoreset", "lmaze_observe", "lmaze_reset",
-           "lmaze_render_expanded", "lmaze_foveal_step", "lmaze_foveal_reset", "lmaze_v1_set_foveal_goal",
+           "lmaze_episode_stats", "lmaze_render_expanded", "lmaze_foveal_step", "lmaze_foveal_reset", "lmaze_v1_set_foveal_goal",
            "lmaze_v5_planner_step", "lmaze_v6_safe_foveal_goal", "lmaze_expand_planes")
 
 
@@ -84,6 +84,8 @@ def _load():
     lib.lmaze_reset.argtypes = [P, vp, vp, u64, u64, i64, vp, vp, vp, vp, vp, vp, i64, vp]
     lib.lmaze_render_expanded.restype = C.c_int
     lib.lmaze_render_expanded.argtypes = [vp, i32, i32, C.POINTER(i32), i32, vp, i64, vp]
+    lib.lmaze_episode_stats.restype = C.c_int
+    lib.lmaze_episode_stats.argtypes = [vp, vp, vp, vp, C.c_float, i64, vp, vp]
     FP, FB = C.POINTER(LmazeFovealParams), C.POINTER(LmazeFovealBuffers)
     lib.lmaze_foveal_step.restype = C.c_int
     lib.lmaze_foveal_step.argtypes = [FP, vp, vp, FB, i64, vp]

@@ -188,6 +188,14 @@ int lmaze_reset(const LmazeParams* params, const uint8_t* layout, const uint8_t*
     return (int)launch_step(params->variant, false, a, params->layout_mode, (hipStream_t)stream);
 }
 
+int lmaze_episode_stats(const uint8_t* done, const float* reward, const int32_t* step_count,
+                        const int32_t* goal_count, float reward_goal, int64_t n, int64_t* out4, void* stream) {
+    if (!done || !reward || !step_count || !out4) return LMAZE_E_NULL;
+    if (n < 0 || n > ((int64_t)1 << 40)) return LMAZE_E_COUNT;
+    if (misaligned(out4, 8)) return LMAZE_E_ALIGN;
+    return (int)launch_episode_stats(done, reward, step_count, goal_count, reward_goal, n, out4, (hipStream_t)stream);
+}
+
 int lmaze_render_expanded(const int32_t* obs, int32_t grid, int32_t expansion, const int32_t* channel_mask_host,
                           int32_t channels, float* out, int64_t n, void* stream) {
     if (!obs || !channel_mask_host || !out) return LMAZE_E_NULL;

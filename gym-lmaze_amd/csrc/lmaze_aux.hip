@@ -128,6 +128,48 @@ __global__ __launch_bounds__(LMAZE_BLOCK) void render_expanded_kernel(const Expa
     }
 }
 
+// ------------------------------------------------------------------------------------
+// Episode statistics: four integer sums over the batch (grid-stride, wave shuffles, one 64-bit
+// atomic per workgroup and counter)
+// ------------------------------------------------------------------------------------
+__global__ __launch_bounds__(LMAZE_BLOCK) void episode_stats_kernel(const uint8_t* done, const float* reward,
+                                                                    const int32_t* step_count, const int32_t* goal_count,
+                                                                    float reward_goal, int64_t n,
+                                                                    unsigned long long* out4) {
+    long long acc[4] = {0, 0, 0, 0};
+    for (int64_t i = (int64_t)blockIdx.x * LMAZE_BLOCK + threadIdx.x; i < n; i += (int64_t)gridDim.x * LMAZE_BLOCK) {
+        const bool d = done[i] != 0;
+        acc[0] += d;
+        acc[1] += reward[i] == reward_goal;
+        acc[2] += d ? step_count[i] : 0;
+        if (goal_count) acc[3] += goal_count[i];
+    }
+    __shared__ long long part[4][LMAZE_BLOCK / 64];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        long long v = acc[k];
+        for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+        if ((threadIdx.x & 63) == 0) part[k][threadIdx.x >> 6] = v;
+    }
+    __syncthreads();
+    if (threadIdx.x < 4) {
+        long long v = 0;
+        for (int w = 0; w < LMAZE_BLOCK / 64; ++w) v += part[threadIdx.x][w];
+        if (v) atomicAdd(out4 + threadIdx.x, (unsigned long long)v);
+    }
+}
+
+hipError_t launch_episode_stats(const uint8_t* done, const float* reward, const int32_t* step_count,
+                                const int32_t* goal_count, float reward_goal, int64_t n, int64_t* out4, hipStream_t s) {
+    hipError_t e = hipMemsetAsync(out4, 0, 4 * sizeof(int64_t), s);
+    if (e != hipSuccess || n == 0) return e;
+    int64_t blocks = (n + LMAZE_BLOCK - 1) / LMAZE_BLOCK;
+    if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(episode_stats_kernel, dim3((unsigned)blocks), dim3(LMAZE_BLOCK), 0, s, done, reward, step_count,
+                       goal_count, reward_goal, n, reinterpret_cast<unsigned long long*>(out4));
+    return hipGetLastError();
+}
+
 hipError_t launch_expand(const ExpandArgs& a, hipStream_t s) {
     if (a.n == 0) return hipSuccess;
     const int S = a.grid * a.expansion;

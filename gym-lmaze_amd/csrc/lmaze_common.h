@@ -64,6 +64,8 @@ struct ExpandArgs {
 hipError_t launch_step(int variant, bool do_step, const StepArgs& a, int layout_mode, hipStream_t s);
 hipError_t launch_reset(int variant, const ResetArgs& a, int layout_mode, hipStream_t s);
 hipError_t launch_expand(const ExpandArgs& a, hipStream_t s);
+hipError_t launch_episode_stats(const uint8_t* done, const float* reward, const int32_t* step_count,
+                                const int32_t* goal_count, float reward_goal, int64_t n, int64_t* out4, hipStream_t s);
 
 // static observation bits of one layout cell (include/lmaze.h LMAZE_OBS_*)
 template <int VARIANT>

@@ -306,6 +306,22 @@ class LmazeVecEnv(object):
         _abi.check("lmaze_render_expanded", rc)
         return out
 
+    def episode_stats(self, all_ranks=False):
+        """Counters over the batch, off the step path: {"done", "goal_rewards", "done_steps", "goal_count"}.
+        all_ranks=True sums them over the process group (one all_reduce of four int64 over RCCL): the only
+        collective the library ever issues.  Synchronises (returns Python ints)."""
+        out = torch.empty(4, dtype=torch.int64, device=self.device)
+        with self._guard():
+            rc = _abi.lib.lmaze_episode_stats(self._p_done, self._p_reward, self._p_step,
+                                              None if self._is_v3 else self._p_gc, self.rewards[2], self.num_envs,
+                                              out.data_ptr(), self._stream())
+        _abi.check("lmaze_episode_stats", rc)
+        if all_ranks:
+            from .sharding import sum_over_ranks
+            out = sum_over_ranks(out, device=self.device)
+        v = out.tolist()
+        return {"done": v[0], "goal_rewards": v[1], "done_steps": v[2], "goal_count": v[3]}
+
     def host_state(self):
         """One device->host copy of every per-env scalar; returns numpy views."""
         h = self._state.cpu().numpy()

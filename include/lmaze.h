@@ -176,6 +176,17 @@ int lmaze_render_expanded(const int32_t* obs, int32_t grid, int32_t expansion,
                           const int32_t* channel_mask_host, int32_t channels, float* out,
                           int64_t n, void* stream);
 
+/*
+ * Episode statistics of a batch, off the step path (the reference only keeps goalCount, v0:24,195):
+ * out4 int64[4] (device; zeroed by this call) =
+ *   { #envs with done set, #envs with reward == reward_goal, sum of step_count over the done envs,
+ *     sum of goal_count (0 when goal_count is NULL) }.
+ * Integer sums, so the result does not depend on the order of the reduction.  A multi-GPU run sums
+ * the four numbers over ranks with one all_reduce (the only collective this library ever needs).
+ */
+int lmaze_episode_stats(const uint8_t* done, const float* reward, const int32_t* step_count,
+                        const int32_t* goal_count, float reward_goal, int64_t n, int64_t* out4, void* stream);
+
 /* ====================================================================================== */
 /* Foveal variants: the agent sees a 5x5 window (a8 crop, a9 frame history of SURVEY 8a).  */
 /*   v1 = gym_lmaze/envs/lmaze_env_v1.py   v2 = lmaze_env_v2.py   v4 = lmaze_env_v4.py       */

@@ -162,3 +162,23 @@ def test_autotune_keeps_results_and_state():
             env.step(acts[k])
             ref.step(acts[k])
         assert (env.obs == ref.obs).all() and (env._state == ref._state).all(), hint
+
+
+def test_episode_stats_match_numpy():
+    N, G = 100003, 11
+    lay = L.to_codes(L.open_room(G, (5, 5)))
+    env = PKG.LmazeVecEnv(N, variant="v0", layout=lay, seed=8, step_limit=17)
+    gen = torch.Generator(device="cuda").manual_seed(3)
+    for t in range(40):
+        env.step(torch.randint(0, 4, (N,), dtype=torch.int32, device="cuda", generator=gen), auto_reset=True)
+        if t in (0, 16, 39):
+            s = env.episode_stats()
+            h = env.host_state()
+            assert s["done"] == int(h["done"].sum())
+            assert s["goal_rewards"] == int((h["reward"] == np.float32(100.0)).sum())
+            assert s["done_steps"] == int(h["step_count"][h["done"] != 0].sum())
+            assert s["goal_count"] == int(h["goal_count"].sum())
+    assert s["goal_count"] > 0 and env.episode_stats(all_ranks=True) == s     # no process group: the same numbers
+    v3 = PKG.LmazeVecEnv(5000, variant="v3", seed=1)
+    v3.step(torch.randint(0, 4, (5000,), dtype=torch.int32, device="cuda"))
+    assert v3.episode_stats()["goal_count"] == 0 and v3.episode_stats()["done"] == int(v3.done.sum().item())
