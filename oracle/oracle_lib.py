@@ -10,7 +10,7 @@ import subprocess
 import numpy as np
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "liblmaze_oracle.so")
+LIB_PATH = os.environ.get("LMAZE_ORACLE_LIB") or os.path.join(HERE, "liblmaze_oracle.so")   # override: sanitizer build
 
 VARIANT_V0, VARIANT_V3 = 0, 3
 LAYOUT_SHARED, LAYOUT_PER_ENV = 0, 1
@@ -24,6 +24,8 @@ class Params(C.Structure):
 
 
 def build(force=False):
+    if os.environ.get("LMAZE_ORACLE_LIB"):
+        return LIB_PATH
     src = os.path.join(HERE, "lmaze_oracle.c")
     hdr = os.path.join(os.path.dirname(HERE), "include", "lmaze.h")
     if (force or not os.path.exists(LIB_PATH)
