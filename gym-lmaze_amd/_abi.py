@@ -58,6 +58,14 @@ class LmazeError(RuntimeError):
 
 def _load():
     if not os.path.exists(LIB_PATH):
+        # a fresh checkout: build the library once (hipcc cross-compiles gfx950 without a GPU); this is
+        # still the only implementation -- if the build is impossible the import fails below
+        import subprocess
+        try:
+            subprocess.check_call(["make", "-C", os.path.join(HERE, "csrc"), "-s", "-j4"])
+        except Exception:
+            pass
+    if not os.path.exists(LIB_PATH):
         raise ImportError(
             "gym-lmaze_amd: %s is missing. The HIP library is the only compute path (no CPU fallback); "
             "build it with `make -C %s` (hipcc, --offload-arch=gfx950)." % (LIB_PATH, os.path.join(HERE, "csrc")))

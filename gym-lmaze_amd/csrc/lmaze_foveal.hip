@@ -4,12 +4,14 @@
 //   v2 = gym_lmaze/envs/lmaze_env_v2.py:127-225   25-way teleport inside the fovea, 5 layouts
 //   v4 = gym_lmaze/envs/lmaze_env_v4.py:167-272   v2 + float visit-map plane (whole-plane halving)
 //
+//   v5/v6 = lmaze_env_v5.py:158-292 (plannerStep + step), lmaze_env_v6.py:505-523 (safeFovealGoal)
+//
 // Same two-phase shape as lmaze_step.hip: one lane per env runs the transition against the
-// layout table held in LDS and leaves a small record (window centres, goal, layout row, action)
-// in LDS; then the workgroup's lanes stripe its contiguous observation range float[envs*C*25]
-// with 16-byte stores.  v4 adds a middle phase: the workgroup's visit maps float[envs*G*G] are
-// streamed through (load, +window, halve, store) with 16-byte accesses and kept in LDS for the
-// window samples.  HBM bytes per env-step: v1 436, v2 557, v4 3 349.
+// layout table held in LDS and leaves the env's observation in LDS as 25-bit plane masks; then the
+// workgroup's lanes stripe its contiguous observation range float[envs*C*25] with 16-byte stores.
+// v4-v6 add a middle phase: the visit maps float[envs*G*G] that change are streamed through (load,
+// + window, halve, store) with 16-byte accesses, keeping the cells the windows show in LDS.
+// HBM bytes per env-step: v1 454, v2 545, v4 3 337.
 #include "lmaze_common.h"
 
 namespace lmaze {
@@ -45,12 +47,6 @@ struct EnvRec {           // one env after its transition (registers only; phase
     int16_t upd;          // v5/v6: localDone -> this call halves the visit map (v5:313-318)
     int16_t pad;
 };
-
-__device__ __forceinline__ float free_plane(uint8_t c) { return (c == 'B' || c == 'S' || c == 'X') ? 1.0f : 0.0f; }
-
-__device__ __forceinline__ int channels_of(int variant) {
-    return variant == LMAZE_VARIANT_V1 ? 4 : (variant == LMAZE_VARIANT_V2 ? 5 : 7);
-}
 
 // k-th (row-major) interior cell the reference's rejection loops accept, or the count (k < 0).
 // kind 0: goal (v2:279: not 'W', not 'S'); kind 1: ball (v2:292: not 'W', not 'X', != goal)

@@ -81,3 +81,19 @@ def test_product_never_touches_oracle():
             if f.endswith((".py", ".hip", ".h")):
                 src = open(os.path.join(base, f)).read()
                 assert "oracle" not in src.lower(), os.path.join(base, f)
+
+
+def test_header_is_plain_c(tmp_path):
+    """include/lmaze.h must compile as C99 (the boundary is a C ABI, not a C++ one), and a C caller that
+    fills both parameter structs must agree with the ctypes mirrors on their sizes."""
+    src = tmp_path / "probe.c"
+    src.write_text('#include <stdio.h>\n#include "lmaze.h"\n'
+                   'int main(void){ LmazeParams p = {0}; LmazeFovealParams f = {0}; LmazeFovealBuffers b = {0};\n'
+                   '  (void)p; (void)f; (void)b;\n'
+                   '  printf("%zu %zu %zu\\n", sizeof p, sizeof f, sizeof b); return 0; }\n')
+    exe = tmp_path / "probe"
+    subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Wextra", "-Werror", "-pedantic", "-I", os.path.join(ROOT, "include"),
+                           str(src), "-o", str(exe)])
+    sizes = [int(v) for v in subprocess.check_output([str(exe)], text=True).split()]
+    abi_mod = importlib.import_module("gym-lmaze_amd._abi")
+    assert sizes == [C.sizeof(abi_mod.LmazeParams), C.sizeof(abi_mod.LmazeFovealParams), C.sizeof(abi_mod.LmazeFovealBuffers)]

@@ -367,7 +367,6 @@ def test_dropin_v6_seeded_event_rollout():
     import random
     import gym_lmaze
     g = load_golden("v6_seed0")
-    rs = np.random.RandomState(int(g["seed"]) + 1000)        # the generator's own stream (oracle/gen_golden.py)
     random.seed(int(g["seed"]))
     np.random.seed(int(g["seed"]))
     env = gym_lmaze.make("lmaze-v6")
@@ -377,10 +376,8 @@ def test_dropin_v6_seeded_event_rollout():
             fov = env.reset()
             assert obs_hash(fov) == g["fov_hash"][t], t
         elif ev == 1:
-            # replicate the generator's choice between safeFovealGoal() and a random goal
-            rs_state = None
-            loc = None
-            # (the goal id recorded in the fixture tells which it was; safe goals consume np.random)
+            # the generator either called safeFovealGoal() (which consumes np.random) or drew the goal from
+            # its own stream; the goal id recorded in the fixture tells which it was
             before = np.random.get_state()
             sg = env.safeFovealGoal()
             if sg != arg:
