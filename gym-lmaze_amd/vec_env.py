@@ -306,6 +306,21 @@ class LmazeVecEnv(object):
         _abi.check("lmaze_render_expanded", rc)
         return out
 
+    def capture_rollout(self, actions, auto_reset=False):
+        """Capture the T = actions.shape[0] launches of rollout(actions) into ONE hipGraph and return it
+        (torch.cuda.CUDAGraph; call .replay()).  For launch-bound batch sizes (65 536 x 8x8 is 6 us per
+        step, a third of it launch gap).  The launches allocate nothing and never synchronise, so they are
+        capturable as they are.  With auto_reset the reset epochs are baked into the graph: every replay
+        re-uses the same placement draws."""
+        side = torch.cuda.Stream(device=self.device)
+        side.wait_stream(torch.cuda.current_stream(self.device))
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.stream(side):
+            with torch.cuda.graph(graph, stream=side):
+                self.rollout(actions, auto_reset=auto_reset)
+        torch.cuda.current_stream(self.device).wait_stream(side)
+        return graph
+
     def episode_stats(self, all_ranks=False):
         """Counters over the batch, off the step path: {"done", "goal_rewards", "done_steps", "goal_count"}.
         all_ranks=True sums them over the process group (one all_reduce of four int64 over RCCL): the only

@@ -140,6 +140,17 @@ def test_graph_capture_replays_steps():
     torch.cuda.synchronize()
     assert (env_a.obs == env_b.obs).all() and (env_a.ball_xy == env_b.ball_xy).all()
     assert (env_a.step_count == env_b.step_count).all()
+    # the host helper does the same, and a replay advances the state again
+    env_c = PKG.LmazeVecEnv(N, variant="v0", layout=lay, seed=4)
+    g2 = env_c.capture_rollout(acts)
+    g2.replay()
+    torch.cuda.synchronize()
+    assert (env_c.obs == env_a.obs).all()
+    g2.replay()
+    for t in range(K):
+        env_a.step(acts[t])
+    torch.cuda.synchronize()
+    assert (env_c.obs == env_a.obs).all() and (env_c.step_count == 2 * K).all()
 
 
 def test_autotune_keeps_results_and_state():
