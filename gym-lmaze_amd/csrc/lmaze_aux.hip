@@ -54,6 +54,35 @@ __global__ __launch_bounds__(LMAZE_BLOCK) void reset_perenv_kernel(const ResetAr
     }
 }
 
+// Per-env layouts with G*G a multiple of 256: the layout is read once as dwords into registers
+// (256 B per wave instruction) and ranked there (wave_place_regs), one wave per env.
+template <int VARIANT, int G>
+__global__ __launch_bounds__(LMAZE_BLOCK) void reset_perenv_wave_kernel(const ResetArgs a) {
+    constexpr int CELLS = G * G, NJ = CELLS / 256;
+    const int lane = threadIdx.x & 63;
+    const int64_t e = (int64_t)blockIdx.x * (LMAZE_BLOCK / 64) + (threadIdx.x >> 6);
+    if (e >= a.n) return;
+    if (a.mask && !a.mask[e]) return;
+    const uint32_t* lay32 = reinterpret_cast<const uint32_t*>(a.layout + (size_t)e * CELLS);
+    uint32_t w[NJ];
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) w[j] = lay32[j * 64 + lane];
+    int ball_cell, goal_cell;
+    wave_place_regs<VARIANT, G, NJ>(w, env_draw(a.seed, a.epoch, a.env_base + e), lane, ball_cell, goal_cell);
+    if (lane == 0) {
+        if (goal_cell >= 0) a.goal[e] = make_int2(goal_cell / G, goal_cell % G);
+        if (ball_cell >= 0) a.ball[e] = make_int2(ball_cell / G, ball_cell % G);
+        write_reset(a, e);
+    }
+}
+
+template <int G>
+static bool launch_reset_wave(bool v3, const ResetArgs& a, unsigned blocks, hipStream_t s) {
+    if (v3) hipLaunchKernelGGL((reset_perenv_wave_kernel<LMAZE_VARIANT_V3, G>), dim3(blocks), dim3(LMAZE_BLOCK), 0, s, a);
+    else hipLaunchKernelGGL((reset_perenv_wave_kernel<LMAZE_VARIANT_V0, G>), dim3(blocks), dim3(LMAZE_BLOCK), 0, s, a);
+    return true;
+}
+
 hipError_t launch_reset(int variant, const ResetArgs& a, int layout_mode, hipStream_t s) {
     if (a.n == 0) return hipSuccess;
     const bool v3 = variant == LMAZE_VARIANT_V3;
@@ -65,6 +94,11 @@ hipError_t launch_reset(int variant, const ResetArgs& a, int layout_mode, hipStr
     } else {
         const int epb = LMAZE_BLOCK / 64;
         const unsigned blocks = (unsigned)((a.n + epb - 1) / epb);
+        const bool wave = (a.grid == 16 && launch_reset_wave<16>(v3, a, blocks, s)) ||
+                          (a.grid == 32 && launch_reset_wave<32>(v3, a, blocks, s)) ||
+                          (a.grid == 48 && launch_reset_wave<48>(v3, a, blocks, s)) ||
+                          (a.grid == 64 && launch_reset_wave<64>(v3, a, blocks, s));
+        if (wave) return hipGetLastError();
         if (v3) hipLaunchKernelGGL(reset_perenv_kernel<LMAZE_VARIANT_V3>, dim3(blocks), dim3(LMAZE_BLOCK), 0, s, a);
         else hipLaunchKernelGGL(reset_perenv_kernel<LMAZE_VARIANT_V0>, dim3(blocks), dim3(LMAZE_BLOCK), 0, s, a);
     }

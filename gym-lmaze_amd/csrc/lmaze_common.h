@@ -260,6 +260,88 @@ __device__ __forceinline__ void wave_place(const uint8_t* lay, int G, int CELLS,
     }
 }
 
+// ---- register-tiled placement: the env's layout sits in registers, lane l holding dword 64*j + l in
+// w[j] (cells 4*(64*j + l) .. +3), as in step_perenv_wave_kernel.  Same rule as place_from_list /
+// wave_place: accepted cells are ranked in row-major order, which here is (j, lane, byte) order.
+template <int VARIANT, int G, int NJ>
+__device__ __forceinline__ void lane_spawn_masks(const uint32_t (&w)[NJ], int lane, uint32_t (&ok)[NJ]) {
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+        uint32_t m = 0;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int cell = ((j * 64 + lane) << 2) + q;
+            const int x = cell / G, y = cell - x * G;
+            const bool in = x >= 1 && x <= G - 2 && y >= 1 && y <= G - 2;
+            m |= (uint32_t)(in && spawn_ok<VARIANT>((uint8_t)(w[j] >> (8 * q)))) << q;
+        }
+        ok[j] = m;
+    }
+}
+
+__device__ __forceinline__ int wave_sum(int v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+    return v;
+}
+
+// k-th accepted cell (k wave-uniform, 0-based); every lane returns the same cell, -1 if k is too large
+template <int NJ>
+__device__ __forceinline__ int wave_kth_from_masks(const uint32_t (&ok)[NJ], int k, int lane) {
+    int running = 0;
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+        const int c = __popc(ok[j]);
+        int incl = c;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            const int up = __shfl_up(incl, off, 64);
+            if (lane >= off) incl += up;
+        }
+        const int total = __shfl(incl, 63, 64);
+        if (k < running + total) {
+            const int excl = incl - c;
+            const bool mine = k >= running + excl && k < running + incl;
+            int r = k - running - excl, cell = -1;
+            if (mine) {
+                uint32_t m = ok[j];
+                for (; r > 0; --r) m &= m - 1;  // drop the r lowest set bits
+                cell = ((j * 64 + lane) << 2) + (__ffs((int)m) - 1);
+            }
+            const unsigned long long who = __ballot(mine);
+            return __shfl(cell, __ffsll((long long)who) - 1, 64);
+        }
+        running += total;
+    }
+    return -1;
+}
+
+template <int VARIANT, int G, int NJ>
+__device__ __forceinline__ void wave_place_regs(const uint32_t (&w)[NJ], uint4 r, int lane, int& ball_cell, int& goal_cell) {
+    uint32_t ok[NJ];
+    lane_spawn_masks<VARIANT, G, NJ>(w, lane, ok);
+    int cnt = 0;
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) cnt += __popc(ok[j]);
+    const int count = wave_sum(cnt);
+    ball_cell = -1;
+    goal_cell = -1;
+    if (VARIANT == LMAZE_VARIANT_V3) {
+        int kg = -1;
+        if (count > 0) {
+            kg = (int)__umulhi(r.x, (uint32_t)count);
+            goal_cell = wave_kth_from_masks<NJ>(ok, kg, lane);
+        }
+        if (count > 1) {
+            int kb = (int)__umulhi(r.y, (uint32_t)(count - 1));
+            kb += (kb >= kg);
+            ball_cell = wave_kth_from_masks<NJ>(ok, kb, lane);
+        }
+    } else if (count > 0) {
+        ball_cell = wave_kth_from_masks<NJ>(ok, (int)__umulhi(r.y, (uint32_t)count), lane);
+    }
+}
+
 // OR `bit` into component d (0..3) of v; other d leave v unchanged
 __device__ __forceinline__ void or_at(int4& v, int d, int bit) {
     v.x |= (d == 0) ? bit : 0;

@@ -367,10 +367,9 @@ __global__ __launch_bounds__(LMAZE_BLOCK) void step_perenv_wave_kernel(const Ste
             const int act = a.action[e];
             int sc_in = a.step_count[e];
             float r_in = V3 ? 0.0f : a.reward[e];
-            if (autoreset && a.done[e]) {  // rare: re-place with ballot scans of the layout (L2-hot)
+            if (autoreset && a.done[e]) {  // re-place from the layout registers (wave-uniform branch)
                 int bc, gc;
-                wave_place<VARIANT>(a.layout + (size_t)e * CELLS, G, CELLS, env_draw(a.seed, a.epoch, a.env_base + e), lane,
-                                    bc, gc);
+                wave_place_regs<VARIANT, G, NJ>(w, env_draw(a.seed, a.epoch, a.env_base + e), lane, bc, gc);
                 if (bc >= 0) b = make_int2(bc / G, bc % G);
                 if (V3 && gc >= 0) {
                     g = make_int2(gc / G, gc % G);
