@@ -31,6 +31,7 @@ struct FovealArgs {
     int32_t place;
     uint64_t seed, epoch;
     int64_t env_base;
+    int32_t nt;             // non-temporal observation stores (set by the launcher)
 };
 
 struct EnvRec {           // one env after its transition (registers only; phase 1 turns it into plane masks)
@@ -92,13 +93,15 @@ __device__ __forceinline__ uint32_t onehot_bits(int tx, int ty, int cx, int cy) 
     return (i >= 0 && i < FOV && j >= 0 && j < FOV) ? (1u << (FOV * i + j)) : 0u;
 }
 
-template <int VARIANT, int MODE, int EPB>
+// GT = grid side known at compile time (14 and 18, the reference's sizes; 0: read it from the params):
+// the visit-map stream divides by G for every cell, which is only cheap with a constant
+template <int VARIANT, int MODE, int EPB, int GT>
 __global__ __launch_bounds__(LMAZE_BLOCK) void foveal_kernel(const FovealArgs a) {
     constexpr bool V1 = VARIANT == LMAZE_VARIANT_V1, V5 = VARIANT == LMAZE_VARIANT_V5;
     constexpr bool V4 = VARIANT == LMAZE_VARIANT_V4 || V5;   // "has a visit map"
     constexpr int C = V1 ? 4 : (V4 ? 7 : 5);
     constexpr int PERENV = C * W25;  // floats of observation per env
-    const int G = a.p.grid, CELLS = G * G, L = V1 ? 1 : a.p.n_layouts;
+    const int G = GT ? GT : a.p.grid, CELLS = G * G, L = V1 ? 1 : a.p.n_layouts;
 
     // LDS: per-env plane masks and window centres, the two 5x5 samples of the visit map (v4-v6), one
     // 64-bit row mask per layout row for each static plane, and the layout characters for the transition
@@ -485,7 +488,13 @@ __global__ __launch_bounds__(LMAZE_BLOCK) void foveal_kernel(const FovealArgs a)
             v[k] = element(le, rem);
             if (++rem == PERENV) { rem = 0; ++le; }
         }
-        reinterpret_cast<float4*>(obs)[q] = make_float4(v[0], v[1], v[2], v[3]);
+        if (a.nt) {  // large batches: the observation cannot stay in the Infinity Cache, stream it (+6...12 %)
+            typedef float v4f __attribute__((ext_vector_type(4)));
+            v4f t = {v[0], v[1], v[2], v[3]};
+            __builtin_nontemporal_store(t, reinterpret_cast<v4f*>(obs) + q);
+        } else {
+            reinterpret_cast<float4*>(obs)[q] = make_float4(v[0], v[1], v[2], v[3]);
+        }
     }
     // scalar path: the ragged tail, or every element when some env of the workgroup is skipped
     for (int f = (nq << 2) + tid; f < R; f += LMAZE_BLOCK) {
@@ -611,7 +620,15 @@ static hipError_t launch_foveal_one(const FovealArgs& a, hipStream_t s) {
     size_t lds = (size_t)EPB * 60 + ((size_t)L * a.p.grid + 2 * (size_t)a.p.grid) * 8 + (size_t)((L * cells + 15) & ~15);
     if (VARIANT == LMAZE_VARIANT_V4 || VARIANT == LMAZE_VARIANT_V5) lds += (size_t)EPB * 2 * W25 * 4;
     const int64_t blocks = (a.n + EPB - 1) / EPB;
-    hipLaunchKernelGGL((foveal_kernel<VARIANT, MODE, EPB>), dim3((unsigned)blocks), dim3(LMAZE_BLOCK), lds, s, a);
+    FovealArgs b = a;
+    const int C = VARIANT == LMAZE_VARIANT_V1 ? 4 : (VARIANT == LMAZE_VARIANT_V2 ? 5 : 7);
+    b.nt = (size_t)a.n * C * W25 * 4 > ((size_t)192 << 20);
+    if (a.p.grid == 18)
+        hipLaunchKernelGGL((foveal_kernel<VARIANT, MODE, EPB, 18>), dim3((unsigned)blocks), dim3(LMAZE_BLOCK), lds, s, b);
+    else if (a.p.grid == 14)
+        hipLaunchKernelGGL((foveal_kernel<VARIANT, MODE, EPB, 14>), dim3((unsigned)blocks), dim3(LMAZE_BLOCK), lds, s, b);
+    else
+        hipLaunchKernelGGL((foveal_kernel<VARIANT, MODE, EPB, 0>), dim3((unsigned)blocks), dim3(LMAZE_BLOCK), lds, s, b);
     return hipGetLastError();
 }
 
@@ -665,6 +682,7 @@ static FovealArgs make_foveal_args(const LmazeFovealParams* p, const uint8_t* la
     a.seed = 0;
     a.epoch = 0;
     a.env_base = 0;
+    a.nt = 0;
     return a;
 }
 
