@@ -44,6 +44,8 @@ def lib():
         build()
         _lib = C.CDLL(LIB_PATH)
         _lib.lmaze_oracle_threads.restype = C.c_int
+        # a GPU box shows 256 hardware threads but shares them: stay well inside its process/thread guard
+        _lib.lmaze_oracle_set_threads(C.c_int(max(1, min(32, len(os.sched_getaffinity(0))))))
     return _lib
 
 

@@ -388,3 +388,32 @@ def test_render_expanded_matches_oracle(G, E, cmask):
                                        torch.cuda.current_stream().cuda_stream)
     assert rc == 0
     assert (_np(out).view(np.uint32) == ref.view(np.uint32)).all()
+
+
+def test_empty_batch_and_bad_arguments_on_device():
+    """n = 0 is a no-op on every entry point; rejected arguments launch nothing and report why."""
+    import ctypes as C
+    abi = importlib.import_module("gym-lmaze_amd._abi")
+    env = PKG.LmazeVecEnv(8, variant="v0")
+    st = torch.cuda.current_stream().cuda_stream
+    before = env._state.clone()
+    a = torch.zeros(8, dtype=torch.int32, device="cuda")
+    assert abi.lib.lmaze_step_v0(env._pp, env._p_layout, a.data_ptr(), env._p_ball, env._p_step, env._p_reward,
+                                 env._p_done, env._p_gc, env._p_obs, 0, st) == 0
+    assert abi.lib.lmaze_reset(env._pp, env._p_layout, None, 1, 1, 0, env._p_ball, None, env._p_step, env._p_reward,
+                               env._p_done, env._p_obs, 0, st) == 0
+    m = (C.c_int32 * 4)(1, 2, 4, 8)
+    assert abi.lib.lmaze_render_expanded(env._p_obs, 12, 7, m, 4, env._p_obs, 0, st) == 0
+    torch.cuda.synchronize()
+    assert (env._state == before).all()
+    # misaligned obs pointer -> LMAZE_E_ALIGN, unknown layout mode -> LMAZE_E_LAYOUT; nothing runs
+    assert abi.lib.lmaze_step_v0(env._pp, env._p_layout, a.data_ptr(), env._p_ball, env._p_step, env._p_reward,
+                                 env._p_done, env._p_gc, env._p_obs + 4, 8, st) == -6
+    bad = abi.make_params(abi.VARIANT_V0, 12, 7, 100, -1.0, -0.01, 100.0)
+    assert abi.lib.lmaze_step_v0(C.byref(bad), env._p_layout, a.data_ptr(), env._p_ball, env._p_step, env._p_reward,
+                                 env._p_done, env._p_gc, env._p_obs, 8, st) == -4
+    torch.cuda.synchronize()
+    assert (env._state == before).all()
+    f = PKG.LmazeFovealVecEnv(4, variant="v2")
+    assert abi.lib.lmaze_foveal_step(f._pp, f._p_layouts, a.data_ptr(), f._pb, 0, st) == 0
+    assert abi.lib.lmaze_foveal_step(f._pp, f._p_layouts, None, f._pb, 4, st) == -1
