@@ -34,18 +34,42 @@ __device__ __forceinline__ void store16(int4* p, const int4& v) {
     }
 }
 
-// one env of phase 1; returns the env's ball (and goal) cell index for phase 2
+// One env's inputs, loaded into registers BEFORE the workgroup's LDS set-up and first barrier so
+// that the two global round trips (layout, state) overlap instead of chaining: at launch-bound
+// batch sizes (65 536 x 8x8) the kernel is nothing but that latency chain.
+struct EnvIn {
+    int2 b, g;
+    int act, sc, was_done;
+    float r;
+};
+
 template <int VARIANT, bool DO_STEP>
-__device__ __forceinline__ void env_phase1(const StepArgs& a, const uint8_t* lay, int G, int64_t e,
+__device__ __forceinline__ EnvIn load_env(const StepArgs& a, int64_t e) {
+    constexpr bool V3 = VARIANT == LMAZE_VARIANT_V3;
+    EnvIn in;
+    in.b = a.ball[e];
+    in.g = make_int2(-1, -1);
+    if (V3) in.g = a.goal[e];
+    in.act = 0; in.sc = 0; in.was_done = 0; in.r = 0.0f;
+    if (DO_STEP) {
+        in.act = a.action[e];
+        in.sc = a.step_count[e];
+        if (!V3) in.r = a.reward[e];
+        if (a.auto_reset) in.was_done = a.done[e];
+    }
+    return in;
+}
+
+// one env of phase 1 (layout in LDS); returns the env's ball (and goal) cell index for phase 2
+template <int VARIANT, bool DO_STEP>
+__device__ __forceinline__ void env_phase1(const StepArgs& a, const uint8_t* lay, int G, int64_t e, EnvIn in,
                                            const uint16_t* spawn, int spawn_count, int& ball_cell, int& goal_cell) {
     constexpr bool V3 = VARIANT == LMAZE_VARIANT_V3;
-    int2 b = a.ball[e];
-    int2 g = make_int2(-1, -1);
-    if (V3) g = a.goal[e];
+    int2 b = in.b, g = in.g;
     if (DO_STEP) {
-        int sc_in = a.step_count[e];
-        float r_in = V3 ? 0.0f : a.reward[e];
-        if (a.auto_reset && a.done[e]) {  // reference reset(): placement + zeroed counters
+        int sc_in = in.sc;
+        float r_in = in.r;
+        if (a.auto_reset && in.was_done) {  // reference reset(): placement + zeroed counters
             int bc, gc;
             place_from_list<VARIANT>(spawn, spawn_count, env_draw(a.seed, a.epoch, a.env_base + e), bc, gc);
             if (bc >= 0) b = make_int2(bc / G, bc % G);
@@ -57,7 +81,18 @@ __device__ __forceinline__ void env_phase1(const StepArgs& a, const uint8_t* lay
             r_in = -0.0f;   // v0:109
         }
         int bx = clampi(b.x, 0, G - 1), by = clampi(b.y, 0, G - 1);
-        transition<VARIANT>(a, lay, G, e, sc_in, r_in, bx, by, g.x, g.y);
+        const int sc = sc_in + 1;  // v0:151, v3:225
+        int ox, oy;
+        decode_action(in.act, ox, oy);
+        const int tx = clampi(bx + ox, 0, G - 1), ty = clampi(by + oy, 0, G - 1);
+        float r;
+        bool dn;
+        if (transition_rule<VARIANT>(a, lay[tx * G + ty], ox, oy, tx, ty, sc, r_in, g.x, g.y, bx, by, r, dn) && a.goal_count)
+            a.goal_count[e] += 1;
+        a.ball[e] = make_int2(bx, by);
+        a.step_count[e] = sc;
+        a.reward[e] = r;
+        a.done[e] = dn ? 1 : 0;
         b = make_int2(bx, by);
     } else {
         b = make_int2(clampi(b.x, 0, G - 1), clampi(b.y, 0, G - 1));
@@ -73,7 +108,7 @@ __device__ __forceinline__ void env_phase1(const StepArgs& a, const uint8_t* lay
 template <int GT, int VARIANT, bool DO_STEP, int EPB, bool NT>
 __global__ __launch_bounds__(LMAZE_BLOCK) void step_shared_kernel(const StepArgs a) {
     constexpr bool V3 = VARIANT == LMAZE_VARIANT_V3;
-    static_assert(EPB % 4 == 0, "group alignment");
+    static_assert(EPB % 4 == 0 && EPB <= LMAZE_BLOCK, "group alignment; one lane per env");
     const int G = GT ? GT : a.grid;
     const int CELLS = G * G;
     // envs per 16-byte period of the obs stream: G even -> an env is a whole number of
@@ -96,6 +131,9 @@ __global__ __launch_bounds__(LMAZE_BLOCK) void step_shared_kernel(const StepArgs
     const bool masked = !DO_STEP && a.mask != nullptr;
     const bool autoreset = DO_STEP && a.auto_reset;
 
+    EnvIn in{};
+    if (tid < nb) in = load_env<VARIANT, DO_STEP>(a, blockbase + tid);
+
     for (int i = tid; i < CELLS; i += LMAZE_BLOCK) lay[i] = a.layout[i];
     for (int i = tid; i < PAT; i += LMAZE_BLOCK) {
         const int c = (GT != 0 && GRP > 1) ? i % CELLS : i;
@@ -107,12 +145,13 @@ __global__ __launch_bounds__(LMAZE_BLOCK) void step_shared_kernel(const StepArgs
     }
     __syncthreads();
 
-    for (int le = tid; le < EPB; le += LMAZE_BLOCK) {  // one lane per env
+    if (tid < EPB) {  // one lane per env
+        const int le = tid;
         int bf = -8, gf = -8, mf = 0;
         if (le < nb) {
             const int64_t e = blockbase + le;
             int bc, gc;
-            env_phase1<VARIANT, DO_STEP>(a, lay, G, e, spawn, autoreset ? spawn_count_s : 0, bc, gc);
+            env_phase1<VARIANT, DO_STEP>(a, lay, G, e, in, spawn, autoreset ? spawn_count_s : 0, bc, gc);
             const int off = (GT != 0) ? (le % GRP) * CELLS : 0;
             bf = off + bc;
             if (V3 && gc >= 0) gf = off + gc;
@@ -222,10 +261,12 @@ __global__ __launch_bounds__(LMAZE_BLOCK) void step_perenv_kernel(const StepArgs
     const bool autoreset = DO_STEP && a.auto_reset;
     const bool masked = !DO_STEP && a.mask != nullptr;
 
+    EnvIn in{};  // this lane's env, loaded while the layouts are still on their way
+    if (tid < nb) in = load_env<VARIANT, DO_STEP>(a, blockbase + tid);
     if (tid <= EPB) {
         int f = 0;
         if (tid < nb) {
-            if (autoreset) f = a.done[blockbase + tid] != 0;
+            if (autoreset) f = in.was_done != 0;
             if (masked) f = a.mask[blockbase + tid] != 0;
         }
         flag[tid] = f;
@@ -254,12 +295,10 @@ __global__ __launch_bounds__(LMAZE_BLOCK) void step_perenv_kernel(const StepArgs
         int bcell = -8, gcell = -8;
         if (tid < nb) {
             const int64_t e = blockbase + tid;
-            int2 b = a.ball[e];
-            int2 g = make_int2(-1, -1);
-            if (V3) g = a.goal[e];
+            int2 b = in.b, g = in.g;
             if (DO_STEP) {
-                int sc_in = a.step_count[e];
-                float r_in = V3 ? 0.0f : a.reward[e];
+                int sc_in = in.sc;
+                float r_in = in.r;
                 if (autoreset && flag[tid]) {
                     const int bc = newball[tid], gc = newgoal[tid];
                     if (bc >= 0) b = make_int2(bc / G, bc % G);
@@ -271,7 +310,19 @@ __global__ __launch_bounds__(LMAZE_BLOCK) void step_perenv_kernel(const StepArgs
                     r_in = -0.0f;
                 }
                 int bx = clampi(b.x, 0, G - 1), by = clampi(b.y, 0, G - 1);
-                transition<VARIANT>(a, tile + tid * CELLS, G, e, sc_in, r_in, bx, by, g.x, g.y);
+                const int sc = sc_in + 1;
+                int ox, oy;
+                decode_action(in.act, ox, oy);
+                const int tx = clampi(bx + ox, 0, G - 1), ty = clampi(by + oy, 0, G - 1);
+                float r;
+                bool dn;
+                if (transition_rule<VARIANT>(a, tile[tid * CELLS + tx * G + ty], ox, oy, tx, ty, sc, r_in, g.x, g.y, bx, by,
+                                             r, dn) && a.goal_count)
+                    a.goal_count[e] += 1;
+                a.ball[e] = make_int2(bx, by);
+                a.step_count[e] = sc;
+                a.reward[e] = r;
+                a.done[e] = dn ? 1 : 0;
                 b = make_int2(bx, by);
             } else {
                 b = make_int2(clampi(b.x, 0, G - 1), clampi(b.y, 0, G - 1));
