@@ -19,7 +19,6 @@ import random
 import numpy as np
 import torch
 
-from . import _abi
 from . import layouts as L
 from .compat import Box, Discrete, Env
 from .vec_env import LmazeVecEnv
