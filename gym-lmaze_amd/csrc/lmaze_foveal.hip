@@ -49,20 +49,58 @@ struct EnvRec {           // one env after its transition (registers only; phase
     int16_t pad;
 };
 
-// k-th (row-major) interior cell the reference's rejection loops accept, or the count (k < 0).
-// kind 0: goal (v2:279: not 'W', not 'S'); kind 1: ball (v2:292: not 'W', not 'X', != goal)
-__device__ __forceinline__ int count_or_kth(const uint8_t* lay, int G, int kind, int goal_cell, int k) {
+// Placement on row masks.  rows[x] has bit y set when interior cell (x, y) is accepted; accepted cells are
+// ranked in row-major order, as the oracle's byte scan ranks them.
+__device__ __forceinline__ int mask_count(const uint64_t* rows, int G) {
     int cnt = 0;
-    for (int x = 1; x <= G - 2; ++x)
-        for (int y = 1; y <= G - 2; ++y) {
-            const uint8_t c = lay[x * G + y];
-            const bool ok = kind == 0 ? (c != 'W' && c != 'S') : (c != 'W' && c != 'X' && x * G + y != goal_cell);
-            if (ok) {
-                if (cnt == k) return x * G + y;
-                ++cnt;
-            }
+    for (int x = 1; x <= G - 2; ++x) cnt += __popcll(rows[x]);
+    return cnt;
+}
+
+// rank of cell (gx, gy) among the accepted cells (number of accepted cells before it)
+__device__ __forceinline__ int mask_rank(const uint64_t* rows, int G, int gx, int gy) {
+    int cnt = 0;
+    for (int x = 1; x < gx && x <= G - 2; ++x) cnt += __popcll(rows[x]);
+    if (gx >= 1 && gx <= G - 2) cnt += __popcll(rows[gx] & ((1ull << gy) - 1ull));
+    return cnt;
+}
+
+// k-th accepted cell (0-based) as x*G + y, or -1
+__device__ __forceinline__ int mask_kth(const uint64_t* rows, int G, int k) {
+    for (int x = 1; x <= G - 2; ++x) {
+        uint64_t m = rows[x];
+        const int c = __popcll(m);
+        if (k < c) {
+            for (; k > 0; --k) m &= m - 1;
+            return x * G + (__ffsll((long long)m) - 1);
         }
-    return k < 0 ? cnt : -1;
+        k -= c;
+    }
+    return -1;
+}
+
+// reset() placement of v2/v4/v5/v6 on one layout (v2:277-296): goal uniform over interior cells that are
+// not 'W' and not 'S'; ball uniform over interior cells that are not 'W', not 'X' and not the goal
+__device__ __forceinline__ void place_goal_ball(const uint64_t* goal_rows, const uint64_t* ball_rows, int G, uint4 d,
+                                                int& goal_cell, int& ball_cell) {
+    goal_cell = -1;
+    ball_cell = -1;
+    const int cg = mask_count(goal_rows, G);
+    if (cg > 0) goal_cell = mask_kth(goal_rows, G, (int)__umulhi(d.x, (uint32_t)cg));
+    int cb = mask_count(ball_rows, G);
+    int skip_rank = -1;   // the goal's rank in the ball list when it is in it (a 'B' goal cell)
+    if (goal_cell >= 0) {
+        const int gx = goal_cell / G, gy = goal_cell % G;
+        if ((ball_rows[gx] >> gy) & 1ull) {
+            skip_rank = mask_rank(ball_rows, G, gx, gy);
+            --cb;
+        }
+    }
+    if (cb > 0) {
+        int kb = (int)__umulhi(d.y, (uint32_t)cb);
+        if (skip_rank >= 0 && kb >= skip_rank) ++kb;
+        ball_cell = mask_kth(ball_rows, G, kb);
+    }
 }
 
 // numpy index semantics on an axis of 5: -5..-1 wrap, anything else outside 0..4 raises (-> -1)
@@ -112,7 +150,9 @@ __global__ __launch_bounds__(LMAZE_BLOCK) void foveal_kernel(const FovealArgs a)
     int32_t* flags = reinterpret_cast<int32_t*>(cen + EPB * 4);            // [EPB]     bit0 skip, bit1 visit update
     float* vwin = reinterpret_cast<float*>(flags + EPB);                   // [EPB][2][25] visit-map samples (v4-v6)
     uint64_t* rowfree = reinterpret_cast<uint64_t*>(vwin + (V4 ? EPB * 2 * W25 : 0));  // [L*G] free = B|S|X
-    uint64_t* rowwall = rowfree + L * G;                                   // [G] v1: 'W'
+    uint64_t* rowgoal = rowfree + L * G;                                   // [L*G] interior, not 'W', not 'S' (v2:279)
+    uint64_t* rowball = rowgoal + L * G;                                   // [L*G] interior, not 'W', not 'X' (v2:292)
+    uint64_t* rowwall = rowball + L * G;                                   // [G] v1: 'W'
     uint64_t* rowx = rowwall + G;                                          // [G] v1: 'X'
     uint8_t* lays = reinterpret_cast<uint8_t*>(rowx + G);                  // [L*CELLS]
     __shared__ int any_skip;
@@ -133,6 +173,14 @@ __global__ __launch_bounds__(LMAZE_BLOCK) void foveal_kernel(const FovealArgs a)
         }
         rowfree[i] = fr;
         if (V1) { rowwall[i] = wl; rowx[i] = xx; }
+        if (!V1 && MODE == FM_RESET) {
+            uint64_t ss = 0;
+            for (int y = 0; y < G; ++y) ss |= (uint64_t)(lays[i * G + y] == 'S') << y;
+            const int x = i % G;
+            const uint64_t interior = (x >= 1 && x <= G - 2) ? (((1ull << (G - 2)) - 1ull) << 1) : 0ull;
+            rowgoal[i] = fr & ~ss & interior;      // B or X
+            rowball[i] = fr & ~xx & interior;      // B or S
+        }
     }
     __syncthreads();
 
@@ -269,18 +317,14 @@ __global__ __launch_bounds__(LMAZE_BLOCK) void foveal_kernel(const FovealArgs a)
                     const uint4 d = env_draw(a.seed, a.epoch, a.env_base + e);
                     lid = (int)__umulhi(d.z, (uint32_t)L);             // v5:105 setGrid first
                     a.b.layout_id[e] = lid;
-                    const uint8_t* lay = lays + lid * CELLS;
-                    const int cg = count_or_kth(lay, G, 0, -1, -1);
-                    int goal_cell = -1;
-                    if (cg > 0) {
-                        goal_cell = count_or_kth(lay, G, 0, -1, (int)__umulhi(d.x, (uint32_t)cg));
+                    int goal_cell, ball_cell;
+                    place_goal_ball(rowgoal + lid * G, rowball + lid * G, G, d, goal_cell, ball_cell);
+                    if (goal_cell >= 0) {
                         gx = goal_cell / G; gy = goal_cell % G;
                         a.b.goal_xy[2 * e] = gx; a.b.goal_xy[2 * e + 1] = gy;
                     }
-                    const int cb = count_or_kth(lay, G, 1, goal_cell, -1);
-                    if (cb > 0) {
-                        const int cell = count_or_kth(lay, G, 1, goal_cell, (int)__umulhi(d.y, (uint32_t)cb));
-                        bx = cell / G; by = cell % G;
+                    if (ball_cell >= 0) {
+                        bx = ball_cell / G; by = ball_cell % G;
                         a.b.ball_xy[2 * e] = bx; a.b.ball_xy[2 * e + 1] = by;
                     }
                 }
@@ -341,18 +385,14 @@ __global__ __launch_bounds__(LMAZE_BLOCK) void foveal_kernel(const FovealArgs a)
                     const int lid_new = (int)__umulhi(d.z, (uint32_t)L);
                     if (V4) lid = lid_new;                             // v4:97 setGrid first
                     lid = clampi(lid, 0, L - 1);
-                    const uint8_t* lay = lays + lid * CELLS;
-                    const int cg = count_or_kth(lay, G, 0, -1, -1);
-                    int goal_cell = -1;
-                    if (cg > 0) {
-                        goal_cell = count_or_kth(lay, G, 0, -1, (int)__umulhi(d.x, (uint32_t)cg));
+                    int goal_cell, ball_cell;
+                    place_goal_ball(rowgoal + lid * G, rowball + lid * G, G, d, goal_cell, ball_cell);
+                    if (goal_cell >= 0) {
                         gx = goal_cell / G; gy = goal_cell % G;
                         a.b.goal_xy[2 * e] = gx; a.b.goal_xy[2 * e + 1] = gy;
                     }
-                    const int cb = count_or_kth(lay, G, 1, goal_cell, -1);
-                    if (cb > 0) {
-                        const int cell = count_or_kth(lay, G, 1, goal_cell, (int)__umulhi(d.y, (uint32_t)cb));
-                        bx = cell / G; by = cell % G;
+                    if (ball_cell >= 0) {
+                        bx = ball_cell / G; by = ball_cell % G;
                         a.b.ball_xy[2 * e] = bx; a.b.ball_xy[2 * e + 1] = by;
                     }
                     lid = lid_new;                                     // v2:92 setGrid last
@@ -617,7 +657,7 @@ static hipError_t launch_foveal_one(const FovealArgs& a, hipStream_t s) {
     const int cells = a.p.grid * a.p.grid;
     const int L = VARIANT == LMAZE_VARIANT_V1 ? 1 : a.p.n_layouts;
     // masks 32 B + lmasks 16 B + centres 8 B + flags 4 B per env, row masks, layout characters, visit samples
-    size_t lds = (size_t)EPB * 60 + ((size_t)L * a.p.grid + 2 * (size_t)a.p.grid) * 8 + (size_t)((L * cells + 15) & ~15);
+    size_t lds = (size_t)EPB * 60 + (3 * (size_t)L * a.p.grid + 2 * (size_t)a.p.grid) * 8 + (size_t)((L * cells + 15) & ~15);
     if (VARIANT == LMAZE_VARIANT_V4 || VARIANT == LMAZE_VARIANT_V5) lds += (size_t)EPB * 2 * W25 * 4;
     const int64_t blocks = (a.n + EPB - 1) / EPB;
     FovealArgs b = a;
