@@ -337,6 +337,17 @@ class LmazeVecEnv(object):
         v = out.tolist()
         return {"done": v[0], "goal_rewards": v[1], "done_steps": v[2], "goal_count": v[3]}
 
+    def planes(self, out=None):
+        """The reference's unexpanded planes float32[N,C,G,G] (what it calls retState, lmaze_env.py:208-215):
+        the x1 case of the expanded render, ready as network input."""
+        N, G, Cn = self.num_envs, self.grid, len(self.channel_mask)
+        if out is None:
+            out = torch.empty((N, Cn, G, G), dtype=torch.float32, device=self.device)
+        with self._guard():
+            rc = _abi.lib.lmaze_render_expanded(self._p_obs, G, 1, self._cmask, Cn, out.data_ptr(), N, self._stream())
+        _abi.check("lmaze_render_expanded", rc)
+        return out
+
     def host_state(self):
         """One device->host copy of every per-env scalar; returns numpy views."""
         h = self._state.cpu().numpy()

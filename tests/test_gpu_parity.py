@@ -226,6 +226,15 @@ def test_small_and_ragged_batches(N):
     _compare_rollout("v0", N, 11, 8, shared=False, seed=N)
 
 
+def test_planes_are_the_bit_tests_of_the_compact_obs():
+    env = PKG.LmazeVecEnv(500, variant="v3", seed=2)
+    env.step(torch.randint(0, 4, (500,), dtype=torch.int32))
+    p = env.planes()
+    o = env.obs
+    want = torch.stack([((o & m) != 0).float() for m in env.channel_mask], dim=1)
+    assert p.shape == (500, 3, 18, 18) and (p == want).all()
+
+
 def test_transition_only_leaves_obs_untouched():
     env = PKG.LmazeVecEnv(1000, variant="v0", layout=L.open_room(11, (5, 5)))
     before = env.obs.clone()
