@@ -22,7 +22,7 @@ MAX_GRID, MAX_CHANNELS = 64, 8
 # checks this list and the loaded library against it)
 SYMBOLS = ("lmaze_abi_version", "lmaze_strerror", "lmaze_device_info", "lmaze_step_v0", "lmaze_step_v3",
            "lmaze_step_v0_autoreset", "lmaze_step_v3_autoreset", "lmaze_observe", "lmaze_reset",
-           "lmaze_episode_stats", "lmaze_render_expanded", "lmaze_foveal_step", "lmaze_foveal_reset", "lmaze_v1_set_foveal_goal",
+           "lmaze_episode_stats", "lmaze_render_expanded", "lmaze_foveal_step", "lmaze_foveal_step_autoreset", "lmaze_foveal_reset", "lmaze_v1_set_foveal_goal",
            "lmaze_v5_planner_step", "lmaze_v6_safe_foveal_goal", "lmaze_expand_planes")
 
 
@@ -97,6 +97,8 @@ def _load():
     FP, FB = C.POINTER(LmazeFovealParams), C.POINTER(LmazeFovealBuffers)
     lib.lmaze_foveal_step.restype = C.c_int
     lib.lmaze_foveal_step.argtypes = [FP, vp, vp, FB, i64, vp]
+    lib.lmaze_foveal_step_autoreset.restype = C.c_int
+    lib.lmaze_foveal_step_autoreset.argtypes = [FP, vp, vp, FB, i64, u64, u64, i64, vp]
     lib.lmaze_foveal_reset.restype = C.c_int
     lib.lmaze_foveal_reset.argtypes = [FP, vp, vp, i32, u64, u64, i64, FB, i64, vp]
     lib.lmaze_v1_set_foveal_goal.restype = C.c_int

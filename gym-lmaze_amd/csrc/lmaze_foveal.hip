@@ -32,6 +32,7 @@ struct FovealArgs {
     uint64_t seed, epoch;
     int64_t env_base;
     int32_t nt;             // non-temporal observation stores (set by the launcher)
+    int32_t auto_reset;     // step: an env whose done flag is set on entry is reset first (v1, v2, v4)
 };
 
 struct EnvRec {           // one env after its transition (registers only; phase 1 turns it into plane masks)
@@ -50,7 +51,7 @@ struct EnvRec {           // one env after its transition (registers only; phase
 };
 
 // Placement on row masks.  rows[x] has bit y set when interior cell (x, y) is accepted; accepted cells are
-// ranked in row-major order, as the oracle's byte scan ranks them.
+// ranked in row-major order (the order of the reference's own scan over the grid).
 __device__ __forceinline__ int mask_count(const uint64_t* rows, int G) {
     int cnt = 0;
     for (int x = 1; x <= G - 2; ++x) cnt += __popcll(rows[x]);
@@ -133,7 +134,9 @@ __device__ __forceinline__ uint32_t onehot_bits(int tx, int ty, int cx, int cy) 
 
 // GT = grid side known at compile time (14 and 18, the reference's sizes; 0: read it from the params):
 // the visit-map stream divides by G for every cell, which is only cheap with a constant
-template <int VARIANT, int MODE, int EPB, int GT>
+// AR = fused auto-reset compiled in (a separate instantiation: the extra state it threads through the
+// visit-map stream costs the plain step 20 % when it is only a run-time flag)
+template <int VARIANT, int MODE, int EPB, int GT, bool AR>
 __global__ __launch_bounds__(LMAZE_BLOCK) void foveal_kernel(const FovealArgs a) {
     constexpr bool V1 = VARIANT == LMAZE_VARIANT_V1, V5 = VARIANT == LMAZE_VARIANT_V5;
     constexpr bool V4 = VARIANT == LMAZE_VARIANT_V4 || V5;   // "has a visit map"
@@ -147,8 +150,9 @@ __global__ __launch_bounds__(LMAZE_BLOCK) void foveal_kernel(const FovealArgs a)
     uint32_t* masks = reinterpret_cast<uint32_t*>(lds4);                   // [EPB][8]  25-bit planes of obs
     uint32_t* lmasks = masks + EPB * 8;                                    // [EPB][4]  planes of obs_local (v5/v6)
     int16_t* cen = reinterpret_cast<int16_t*>(lmasks + EPB * 4);           // [EPB][4]  cx, cy, px, py
-    int32_t* flags = reinterpret_cast<int32_t*>(cen + EPB * 4);            // [EPB]     bit0 skip, bit1 visit update
-    float* vwin = reinterpret_cast<float*>(flags + EPB);                   // [EPB][2][25] visit-map samples (v4-v6)
+    int32_t* flags = reinterpret_cast<int32_t*>(cen + EPB * 4);            // [EPB]     bit0 skip, bit1 visit update, bit2 fresh episode, bit3 not stepped
+    int16_t* rcen = reinterpret_cast<int16_t*>(flags + EPB);               // [EPB][2]  ball a fused reset placed (visit map re-init)
+    float* vwin = reinterpret_cast<float*>(rcen + EPB * 2);                // [EPB][2][25] visit-map samples (v4-v6)
     uint64_t* rowfree = reinterpret_cast<uint64_t*>(vwin + (V4 ? EPB * 2 * W25 : 0));  // [L*G] free = B|S|X
     uint64_t* rowgoal = rowfree + L * G;                                   // [L*G] interior, not 'W', not 'S' (v2:279)
     uint64_t* rowball = rowgoal + L * G;                                   // [L*G] interior, not 'W', not 'X' (v2:292)
@@ -173,7 +177,7 @@ __global__ __launch_bounds__(LMAZE_BLOCK) void foveal_kernel(const FovealArgs a)
         }
         rowfree[i] = fr;
         if (V1) { rowwall[i] = wl; rowx[i] = xx; }
-        if (!V1 && MODE == FM_RESET) {
+        if (!V1 && (MODE == FM_RESET || (MODE == FM_STEP && AR))) {
             uint64_t ss = 0;
             for (int y = 0; y < G; ++y) ss |= (uint64_t)(lays[i * G + y] == 'S') << y;
             const int x = i % G;
@@ -190,6 +194,8 @@ __global__ __launch_bounds__(LMAZE_BLOCK) void foveal_kernel(const FovealArgs a)
         EnvRec r;
         r.skip = 0; r.flat = -1; r.action = -1; r.lid = 0; r.gx = r.gy = -9;
         r.b0x = r.b0y = r.b1x = r.b1y = r.f1x = r.f1y = 0; r.upd = 0; r.pad = 0;
+        bool fresh = false, nostep = false;   // fused reset: new episode this call / its step was refused
+        int rx = 0, ry = 0;                   // ball the fused reset placed
         int bx = a.b.ball_xy[2 * e], by = a.b.ball_xy[2 * e + 1];
         r.px = (int16_t)bx; r.py = (int16_t)by;
         if (MODE != FM_STEP && a.mask && !a.mask[e]) r.skip = 1;
@@ -197,8 +203,14 @@ __global__ __launch_bounds__(LMAZE_BLOCK) void foveal_kernel(const FovealArgs a)
             int fgx = a.b.fgoal_xy[2 * e], fgy = a.b.fgoal_xy[2 * e + 1];
             r.action = 1;  // local view unless this is a reset
             if (MODE == FM_STEP) {
+                int sc_in = a.b.step_count[e];
+                if (AR && a.b.done[e]) {                     // fused reset(): v1:82-93
+                    for (int c = 0; c < CELLS; ++c)
+                        if (lays[c] == 'S') { bx = c / G; by = c % G; break; }
+                    sc_in = 0;
+                }
                 const int act = a.action[e];
-                const int sc = a.b.step_count[e] + 1;                  // v1:117
+                const int sc = sc_in + 1;                              // v1:117
                 const int fsc = a.b.foveal_step_count[e] + 1;          // v1:118
                 float fr = -0.0f, rw = -0.0f;                          // v1:120-121
                 bool local_done = false;                               // v1:123
@@ -350,37 +362,10 @@ __global__ __launch_bounds__(LMAZE_BLOCK) void foveal_kernel(const FovealArgs a)
         } else {
             int lid = a.b.layout_id[e];
             int gx = a.b.goal_xy[2 * e], gy = a.b.goal_xy[2 * e + 1];
-            if (MODE == FM_STEP) {
-                const int act = a.action[e];
-                if (act < 0 || act >= W25) {
-                    r.skip = 1;                                        // the reference raises before touching anything
-                } else {
-                    lid = clampi(lid, 0, L - 1);
-                    const uint8_t* lay = lays + lid * CELLS;
-                    float rw = -0.0f;                                  // v2:146
-                    const int sc = a.b.step_count[e] + 1;              // v2:147
-                    const int fx = bx + act / FOV - 2, fy = by + act % FOV - 2;   // v2:151-152
-                    if (fx < G - 2 && fx > 1 && fy < G - 2 && fy > 1) {           // v2:157-159
-                        bx = fx; by = fy;
-                    } else {                                           // v2:160-169
-                        if (fx >= G - 2) bx = G - 3;
-                        if (fx <= 1) bx = 2;
-                        if (fy >= G - 2) by = G - 3;
-                        if (fy <= 1) by = 2;
-                    }
-                    const bool fin = fx >= 0 && fy >= 0 && fx < G && fy < G;
-                    const uint8_t c = fin ? lay[fx * G + fy] : (uint8_t)'W';
-                    if (fx == gx && fy == gy) rw = a.p.reward_goal;    // v2:175-180
-                    else if (c == 'W') rw = a.p.reward_wall;
-                    else if (c == 'B' || c == 'S') rw = a.p.reward_move;
-                    a.b.ball_xy[2 * e] = bx; a.b.ball_xy[2 * e + 1] = by;
-                    a.b.step_count[e] = sc;
-                    a.b.reward[e] = rw;
-                    a.b.done[e] = (rw == a.p.reward_goal || sc > a.p.step_limit) ? 1 : 0;   // v2:222
-                    r.action = (int16_t)act;
-                }
-            } else if (MODE == FM_RESET && !r.skip) {
-                if (a.place) {
+            int sc_in = 0;
+            const bool fused = MODE == FM_STEP && AR && a.b.done[e] != 0;
+            if ((MODE == FM_RESET && !r.skip) || fused) {              // reset(): v2:80-123, v4:95-163
+                if (a.place || fused) {
                     const uint4 d = env_draw(a.seed, a.epoch, a.env_base + e);
                     const int lid_new = (int)__umulhi(d.z, (uint32_t)L);
                     if (V4) lid = lid_new;                             // v4:97 setGrid first
@@ -402,6 +387,41 @@ __global__ __launch_bounds__(LMAZE_BLOCK) void foveal_kernel(const FovealArgs a)
                 a.b.step_count[e] = 0;                                 // v2:86
                 a.b.done[e] = 0;
                 r.px = (int16_t)bx; r.py = (int16_t)by;                // v2:109: previous = current
+                fresh = true;
+                rx = bx; ry = by;
+            } else if (MODE == FM_STEP) {
+                sc_in = a.b.step_count[e];
+            }
+            if (MODE == FM_STEP) {
+                const int act = a.action[e];
+                if (act < 0 || act >= W25) {
+                    if (fresh) nostep = true;                          // reset, then the reference's step() raises
+                    else r.skip = 1;                                   // the reference raises before touching anything
+                } else {
+                    lid = clampi(lid, 0, L - 1);
+                    const uint8_t* lay = lays + lid * CELLS;
+                    float rw = -0.0f;                                  // v2:146
+                    const int sc = sc_in + 1;                          // v2:147
+                    const int fx = bx + act / FOV - 2, fy = by + act % FOV - 2;   // v2:151-152
+                    if (fx < G - 2 && fx > 1 && fy < G - 2 && fy > 1) {           // v2:157-159
+                        bx = fx; by = fy;
+                    } else {                                           // v2:160-169
+                        if (fx >= G - 2) bx = G - 3;
+                        if (fx <= 1) bx = 2;
+                        if (fy >= G - 2) by = G - 3;
+                        if (fy <= 1) by = 2;
+                    }
+                    const bool fin = fx >= 0 && fy >= 0 && fx < G && fy < G;
+                    const uint8_t c = fin ? lay[fx * G + fy] : (uint8_t)'W';
+                    if (fx == gx && fy == gy) rw = a.p.reward_goal;    // v2:175-180
+                    else if (c == 'W') rw = a.p.reward_wall;
+                    else if (c == 'B' || c == 'S') rw = a.p.reward_move;
+                    a.b.ball_xy[2 * e] = bx; a.b.ball_xy[2 * e + 1] = by;
+                    a.b.step_count[e] = sc;
+                    a.b.reward[e] = rw;
+                    a.b.done[e] = (rw == a.p.reward_goal || sc > a.p.step_limit) ? 1 : 0;   // v2:222
+                    r.action = (int16_t)act;
+                }
             }
             r.lid = (int16_t)clampi(lid, 0, L - 1);
             r.gx = (int16_t)gx; r.gy = (int16_t)gy;
@@ -434,7 +454,8 @@ __global__ __launch_bounds__(LMAZE_BLOCK) void foveal_kernel(const FovealArgs a)
             }
         }
         cen[le * 4 + 0] = r.cx; cen[le * 4 + 1] = r.cy; cen[le * 4 + 2] = r.px; cen[le * 4 + 3] = r.py;
-        flags[le] = (r.skip ? 1 : 0) | (r.upd ? 2 : 0);
+        flags[le] = (r.skip ? 1 : 0) | (r.upd ? 2 : 0) | (fresh ? 4 : 0) | (nostep ? 8 : 0);
+        rcen[le * 2] = (int16_t)rx; rcen[le * 2 + 1] = (int16_t)ry;
         if (r.skip) any_skip = 1;
     }
     __syncthreads();
@@ -471,9 +492,17 @@ __global__ __launch_bounds__(LMAZE_BLOCK) void foveal_kernel(const FovealArgs a)
                 const bool skip = fl & 1, upd = fl & 2;
                 if (skip || (V5 && MODE == FM_STEP && !upd)) continue;      // map unchanged: gathered below
                 const int cx = cen[le * 4], cy = cen[le * 4 + 1];
+                const bool fresh = MODE == FM_STEP && AR && (fl & 4), nostep = MODE == FM_STEP && AR && (fl & 8);
                 float4 v = make_float4(0.f, 0.f, 0.f, 0.f);                 // reset: v4:112 / v5:130
-                if (MODE == FM_STEP) v = reinterpret_cast<const float4*>(vis)[q];
-                if (!(V5 && MODE == FM_RESET)) {                            // v5 adds no window at reset
+                if (MODE == FM_STEP && !fresh) v = reinterpret_cast<const float4*>(vis)[q];
+                if (fresh) {                                                // fused reset: v4:112-119 at the placed ball
+                    const int rx = rcen[le * 2], ry = rcen[le * 2 + 1];
+                    v.x = update(v.x, c0, rx, ry);
+                    v.y = update(v.y, c0 + 1, rx, ry);
+                    v.z = update(v.z, c0 + 2, rx, ry);
+                    v.w = update(v.w, c0 + 3, rx, ry);
+                }
+                if (!(V5 && MODE == FM_RESET) && !nostep) {                 // v5 adds no window at reset
                     v.x = update(v.x, c0, cx, cy);
                     v.y = update(v.y, c0 + 1, cx, cy);
                     v.z = update(v.z, c0 + 2, cx, cy);
@@ -489,8 +518,10 @@ __global__ __launch_bounds__(LMAZE_BLOCK) void foveal_kernel(const FovealArgs a)
                 const int fl = flags[le];
                 const bool skip = fl & 1, upd = fl & 2;
                 if (skip || (V5 && MODE == FM_STEP && !upd)) continue;
-                float v = MODE == FM_STEP ? vis[f] : 0.0f;
-                if (!(V5 && MODE == FM_RESET)) v = update(v, c, cen[le * 4], cen[le * 4 + 1]);
+                const bool fresh = MODE == FM_STEP && AR && (fl & 4), nostep = MODE == FM_STEP && AR && (fl & 8);
+                float v = (MODE == FM_STEP && !fresh) ? vis[f] : 0.0f;
+                if (fresh) v = update(v, c, rcen[le * 2], rcen[le * 2 + 1]);
+                if (!(V5 && MODE == FM_RESET) && !nostep) v = update(v, c, cen[le * 4], cen[le * 4 + 1]);
                 vis[f] = v;
                 keep(le, c, v);
             }
@@ -656,19 +687,25 @@ template <int VARIANT, int MODE, int EPB>
 static hipError_t launch_foveal_one(const FovealArgs& a, hipStream_t s) {
     const int cells = a.p.grid * a.p.grid;
     const int L = VARIANT == LMAZE_VARIANT_V1 ? 1 : a.p.n_layouts;
-    // masks 32 B + lmasks 16 B + centres 8 B + flags 4 B per env, row masks, layout characters, visit samples
-    size_t lds = (size_t)EPB * 60 + (3 * (size_t)L * a.p.grid + 2 * (size_t)a.p.grid) * 8 + (size_t)((L * cells + 15) & ~15);
+    // masks 32 B + lmasks 16 B + centres 8 B + flags 4 B + reset centre 4 B per env, row masks, layout characters, visit samples
+    size_t lds = (size_t)EPB * 64 + (3 * (size_t)L * a.p.grid + 2 * (size_t)a.p.grid) * 8 + (size_t)((L * cells + 15) & ~15);
     if (VARIANT == LMAZE_VARIANT_V4 || VARIANT == LMAZE_VARIANT_V5) lds += (size_t)EPB * 2 * W25 * 4;
     const int64_t blocks = (a.n + EPB - 1) / EPB;
     FovealArgs b = a;
     const int C = VARIANT == LMAZE_VARIANT_V1 ? 4 : (VARIANT == LMAZE_VARIANT_V2 ? 5 : 7);
     b.nt = (size_t)a.n * C * W25 * 4 > ((size_t)192 << 20);
-    if (a.p.grid == 18)
-        hipLaunchKernelGGL((foveal_kernel<VARIANT, MODE, EPB, 18>), dim3((unsigned)blocks), dim3(LMAZE_BLOCK), lds, s, b);
-    else if (a.p.grid == 14)
-        hipLaunchKernelGGL((foveal_kernel<VARIANT, MODE, EPB, 14>), dim3((unsigned)blocks), dim3(LMAZE_BLOCK), lds, s, b);
-    else
-        hipLaunchKernelGGL((foveal_kernel<VARIANT, MODE, EPB, 0>), dim3((unsigned)blocks), dim3(LMAZE_BLOCK), lds, s, b);
+    const dim3 grid((unsigned)blocks), block(LMAZE_BLOCK);
+    if constexpr (MODE == FM_STEP && VARIANT != LMAZE_VARIANT_V5) {
+        if (a.auto_reset) {
+            if (a.p.grid == 18) hipLaunchKernelGGL((foveal_kernel<VARIANT, MODE, EPB, 18, true>), grid, block, lds, s, b);
+            else if (a.p.grid == 14) hipLaunchKernelGGL((foveal_kernel<VARIANT, MODE, EPB, 14, true>), grid, block, lds, s, b);
+            else hipLaunchKernelGGL((foveal_kernel<VARIANT, MODE, EPB, 0, true>), grid, block, lds, s, b);
+            return hipGetLastError();
+        }
+    }
+    if (a.p.grid == 18) hipLaunchKernelGGL((foveal_kernel<VARIANT, MODE, EPB, 18, false>), grid, block, lds, s, b);
+    else if (a.p.grid == 14) hipLaunchKernelGGL((foveal_kernel<VARIANT, MODE, EPB, 14, false>), grid, block, lds, s, b);
+    else hipLaunchKernelGGL((foveal_kernel<VARIANT, MODE, EPB, 0, false>), grid, block, lds, s, b);
     return hipGetLastError();
 }
 
@@ -723,6 +760,7 @@ static FovealArgs make_foveal_args(const LmazeFovealParams* p, const uint8_t* la
     a.epoch = 0;
     a.env_base = 0;
     a.nt = 0;
+    a.auto_reset = 0;
     return a;
 }
 
@@ -739,6 +777,23 @@ int lmaze_foveal_step(const LmazeFovealParams* params, const uint8_t* layouts, c
     if (!action) return LMAZE_E_NULL;
     FovealArgs a = make_foveal_args(params, layouts, bufs, n);
     a.action = action;
+    return (int)launch_foveal_mode<FM_STEP>(a, (hipStream_t)stream);
+}
+
+int lmaze_foveal_step_autoreset(const LmazeFovealParams* params, const uint8_t* layouts, const int32_t* action,
+                                const LmazeFovealBuffers* bufs, int64_t n, uint64_t seed, uint64_t epoch,
+                                int64_t env_base, void* stream) {
+    int rc = check_foveal(params, layouts, bufs, n);
+    if (rc) return rc;
+    if (params->variant != LMAZE_VARIANT_V1 && params->variant != LMAZE_VARIANT_V2 && params->variant != LMAZE_VARIANT_V4)
+        return LMAZE_E_VARIANT;
+    if (!action) return LMAZE_E_NULL;
+    FovealArgs a = make_foveal_args(params, layouts, bufs, n);
+    a.action = action;
+    a.auto_reset = 1;
+    a.seed = seed;
+    a.epoch = epoch;
+    a.env_base = env_base;
     return (int)launch_foveal_mode<FM_STEP>(a, (hipStream_t)stream);
 }
 

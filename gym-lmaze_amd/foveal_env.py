@@ -151,13 +151,23 @@ class LmazeFovealVecEnv(object):
         return m, m.data_ptr()
 
     # ------------------------------------------------------------------ the path
-    def step(self, actions):
+    def step(self, actions, auto_reset=False):
         """v1: ids 0..3 (else no move); v2/v4: 0..24 = 5*row+col of the target cell in the window.
-        Returns (obs, reward, done, actions); v1's second stream is in foveal_reward / foveal_done."""
+        Returns (obs, reward, done, actions); v1's second stream is in foveal_reward / foveal_done.
+        auto_reset=True (v1, v2, v4) first resets the envs whose done flag is still set from the previous
+        step, fused into the same kernel: bit-identical to reset(mask=done) + step(actions)."""
         a = self._as_i32(actions, self.num_envs)
         with self._guard():
-            rc = _abi.lib.lmaze_foveal_step(self._pp, self._p_layouts, a.data_ptr(), self._pb, self.num_envs,
-                                            self._stream())
+            if auto_reset:
+                if self._two_level:
+                    raise ValueError("auto_reset is not defined for v5/v6 (episodes restart through planner_step)")
+                rc = _abi.lib.lmaze_foveal_step_autoreset(self._pp, self._p_layouts, a.data_ptr(), self._pb,
+                                                          self.num_envs, self.seed & (2 ** 64 - 1), self._epoch,
+                                                          self.env_base, self._stream())
+                self._epoch += 1
+            else:
+                rc = _abi.lib.lmaze_foveal_step(self._pp, self._p_layouts, a.data_ptr(), self._pb, self.num_envs,
+                                                self._stream())
         _abi.check("lmaze_foveal_step", rc)
         return self.obs, self.reward, self.done, actions
 

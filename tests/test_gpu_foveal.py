@@ -397,3 +397,30 @@ def test_dropin_v6_seeded_event_rollout():
                 assert (out[6][0] == g["fgoal_plane"][t]).all()
         assert (env.ball_x0, env.ball_y0) == tuple(g["ball0"][t]), t
         assert (env.goal_x, env.goal_y) == tuple(g["goal"][t]), t
+
+
+@pytest.mark.parametrize("variant", ["v1", "v2", "v4"])
+def test_foveal_fused_autoreset_equals_reset_then_step(variant):
+    N, T, seed = 3000, (230 if variant == "v1" else 130), 31   # v1 episodes last 200 steps
+    fused = PKG.LmazeFovealVecEnv(N, variant=variant, seed=seed, env_base=9)
+    split = PKG.LmazeFovealVecEnv(N, variant=variant, seed=seed, env_base=9)
+    rs = np.random.RandomState(5)
+    hi = 4 if variant == "v1" else 25
+    n_resets = 0
+    for t in range(T):
+        a = np.where(rs.rand(N) < 0.97, rs.randint(0, hi, N), rs.randint(-2, hi + 3, N)).astype(np.int32)
+        if variant == "v1" and t % 5 == 0:
+            ij = rs.randint(0, 5, (N, 2)).astype(np.int32)
+            fused.set_foveal_goal(ij)
+            split.set_foveal_goal(ij)
+        n_resets += int(split.done.sum().item())
+        split.reset(mask=split.done)
+        split.step(torch.from_numpy(a))
+        fused.step(torch.from_numpy(a), auto_reset=True)
+        hf, hs = fused.host_state(), split.host_state()
+        for k in hf:
+            assert (hf[k].view(np.uint8) == hs[k].view(np.uint8)).all(), (k, t)
+        if variant == "v4":
+            assert (_bits(_np(fused.visit)) == _bits(_np(split.visit))).all(), t
+        assert (_bits(_np(fused.obs)) == _bits(_np(split.obs))).all(), t
+    assert n_resets >= N
