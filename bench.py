@@ -66,6 +66,29 @@ def cpu_baseline(G, layout_codes, budget_s=12.0):
                       % (N, steps, G, G, threads, dt)}
 
 
+def measured_ceiling(pkg, nbytes, dev, reps=20):
+    """The box's own write / copy ceilings: lmaze_bandwidth_probe over a scratch buffer the size
+    of the obs buffer, events on the launch stream.  Reported beside the 8 TB/s peak, never instead of it."""
+    import torch
+    abi = importlib.import_module(pkg.__name__ + "._abi")
+    nbytes = min(int(nbytes), 4 << 30) & ~15
+    src = torch.empty(nbytes // 4, dtype=torch.int32, device=dev)
+    dst = torch.empty_like(src)
+    st = torch.cuda.current_stream(dev).cuda_stream
+    out = {"unit": "GB/s", "bytes": nbytes}
+    with torch.cuda.device(dev):
+        for name, s_ptr, moved in (("fill", None, nbytes), ("copy", src.data_ptr(), 2 * nbytes)):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            for i in range(reps + 5):
+                if i == 5:
+                    e0.record()
+                abi.check("lmaze_bandwidth_probe", abi.lib.lmaze_bandwidth_probe(s_ptr, dst.data_ptr(), nbytes, st))
+            e1.record()
+            torch.cuda.synchronize()
+            out[name] = moved / (e0.elapsed_time(e1) / reps * 1e-3) / 1e9
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -157,9 +180,11 @@ def main():
     actions = torch.randint(0, 4, (R, N), dtype=torch.int32, device=dev, generator=gen)
     row_ptr = [actions[r].data_ptr() for r in range(R)]
 
-    def run(k0, k):
+    def run(k0, k, captured=False):
         for t in range(k0, k0 + k):
-            env.step_raw(row_ptr[t % R], auto_reset=args.auto_reset)
+            # under capture the reset epoch is a device word handed from launch to launch (slot = launch index)
+            env.step_raw(row_ptr[t % R], auto_reset=args.auto_reset,
+                         epoch_slot=(t - k0) if (captured and args.auto_reset) else None)
 
     with torch.cuda.device(dev):
         run(0, args.warmup)
@@ -177,11 +202,13 @@ def main():
             graph = torch.cuda.CUDAGraph()
             with torch.cuda.stream(side):
                 with torch.cuda.graph(graph, stream=side):
-                    run(args.warmup, args.steps)
+                    run(args.warmup, args.steps, captured=True)
             torch.cuda.synchronize()
             t0 = time.perf_counter()
         ev0.record()
         if graph is not None:
+            if args.auto_reset:
+                env.begin_replay(args.steps)
             graph.replay()
         else:
             run(args.warmup, args.steps)
@@ -199,6 +226,8 @@ def main():
         assert int(env.step_count.min().item()) == args.warmup + args.steps
     else:  # episodes restart: nobody is past the step limit, and everybody moved
         assert 1 <= int(env.step_count.min().item()) and int(env.step_count.max().item()) <= env.step_limit
+
+    ceiling = measured_ceiling(pkg, env.obs.numel() * 4, dev) if rank == 0 else None
 
     if rank == 0:
         B = bytes_per_env_step(G, args.per_env_layouts)
@@ -229,7 +258,7 @@ def main():
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "kernel": "lmaze::step_%s_kernel<%d, v0>" % ("perenv" if args.per_env_layouts else "shared", G),
-                         "bytes_per_env_step": B, "kernel_ms_avg": kern_ms},
+                         "bytes_per_env_step": B, "kernel_ms_avg": kern_ms, "measured_ceiling": ceiling},
         }
         if not args.no_cpu_baseline and world == 1:      # rank 0 at N=1 only
             out["cpu_baseline"] = cpu_baseline(G, layout)

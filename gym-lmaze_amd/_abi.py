@@ -10,7 +10,7 @@ import os
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "liblmaze_hip.so")
 
-ABI_VERSION = 1
+ABI_VERSION = 2
 VARIANT_V0, VARIANT_V3 = 0, 3
 VARIANT_V1, VARIANT_V2, VARIANT_V4, VARIANT_V5, VARIANT_V6 = 1, 2, 4, 5, 6
 FOVEA = 5
@@ -22,7 +22,7 @@ MAX_GRID, MAX_CHANNELS = 64, 8
 # checks this list and the loaded library against it)
 SYMBOLS = ("lmaze_abi_version", "lmaze_strerror", "lmaze_device_info", "lmaze_step_v0", "lmaze_step_v3",
            "lmaze_step_v0_autoreset", "lmaze_step_v3_autoreset", "lmaze_observe", "lmaze_reset",
-           "lmaze_episode_stats", "lmaze_render_expanded", "lmaze_foveal_step", "lmaze_foveal_step_autoreset", "lmaze_foveal_reset", "lmaze_v1_set_foveal_goal",
+           "lmaze_episode_stats", "lmaze_bandwidth_probe", "lmaze_render_expanded", "lmaze_foveal_step", "lmaze_foveal_step_autoreset", "lmaze_foveal_reset", "lmaze_v1_set_foveal_goal",
            "lmaze_v5_planner_step", "lmaze_v6_safe_foveal_goal", "lmaze_expand_planes")
 
 
@@ -83,22 +83,24 @@ def _load():
     lib.lmaze_step_v3.restype = C.c_int
     lib.lmaze_step_v3.argtypes = [P, vp, vp, vp, vp, vp, vp, vp, vp, i64, vp]
     lib.lmaze_step_v0_autoreset.restype = C.c_int
-    lib.lmaze_step_v0_autoreset.argtypes = [P, vp, vp, vp, vp, vp, vp, vp, vp, i64, u64, u64, i64, vp]
+    lib.lmaze_step_v0_autoreset.argtypes = [P, vp, vp, vp, vp, vp, vp, vp, vp, i64, u64, u64, i64, vp, vp, vp]
     lib.lmaze_step_v3_autoreset.restype = C.c_int
-    lib.lmaze_step_v3_autoreset.argtypes = [P, vp, vp, vp, vp, vp, vp, vp, vp, i64, u64, u64, i64, vp]
+    lib.lmaze_step_v3_autoreset.argtypes = [P, vp, vp, vp, vp, vp, vp, vp, vp, i64, u64, u64, i64, vp, vp, vp]
     lib.lmaze_observe.restype = C.c_int
     lib.lmaze_observe.argtypes = [P, vp, vp, vp, vp, i64, vp]
     lib.lmaze_reset.restype = C.c_int
     lib.lmaze_reset.argtypes = [P, vp, vp, u64, u64, i64, vp, vp, vp, vp, vp, vp, i64, vp]
     lib.lmaze_render_expanded.restype = C.c_int
     lib.lmaze_render_expanded.argtypes = [vp, i32, i32, C.POINTER(i32), i32, vp, i64, vp]
+    lib.lmaze_bandwidth_probe.restype = C.c_int
+    lib.lmaze_bandwidth_probe.argtypes = [vp, vp, i64, vp]
     lib.lmaze_episode_stats.restype = C.c_int
     lib.lmaze_episode_stats.argtypes = [vp, vp, vp, vp, C.c_float, i64, vp, vp]
     FP, FB = C.POINTER(LmazeFovealParams), C.POINTER(LmazeFovealBuffers)
     lib.lmaze_foveal_step.restype = C.c_int
     lib.lmaze_foveal_step.argtypes = [FP, vp, vp, FB, i64, vp]
     lib.lmaze_foveal_step_autoreset.restype = C.c_int
-    lib.lmaze_foveal_step_autoreset.argtypes = [FP, vp, vp, FB, i64, u64, u64, i64, vp]
+    lib.lmaze_foveal_step_autoreset.argtypes = [FP, vp, vp, FB, i64, u64, u64, i64, vp, vp, vp]
     lib.lmaze_foveal_reset.restype = C.c_int
     lib.lmaze_foveal_reset.argtypes = [FP, vp, vp, i32, u64, u64, i64, FB, i64, vp]
     lib.lmaze_v1_set_foveal_goal.restype = C.c_int

@@ -42,6 +42,8 @@ static StepArgs make_args(const LmazeParams* p, const uint8_t* layout, const int
     a.seed = 0;
     a.epoch = 0;
     a.env_base = 0;
+    a.epoch_in = nullptr;
+    a.epoch_out = nullptr;
     a.goal_rw = nullptr;
     a.mask = nullptr;
     a.launch_hint = p->launch_hint;
@@ -111,24 +113,27 @@ int lmaze_step_v3(const LmazeParams* params, const uint8_t* layout, const int32_
 int lmaze_step_v0_autoreset(const LmazeParams* params, const uint8_t* layout, const int32_t* action,
                             int32_t* ball_xy, int32_t* step_count, float* reward, uint8_t* done,
                             int32_t* goal_count, int32_t* obs, int64_t n, uint64_t seed, uint64_t epoch,
-                            int64_t env_base, void* stream) {
+                            int64_t env_base, const uint64_t* epoch_in_dev, uint64_t* epoch_out_dev, void* stream) {
     int rc = check_params(params, n);
     if (rc) return rc;
     if (params->variant != LMAZE_VARIANT_V0) return LMAZE_E_VARIANT;
     if (!layout || !action || !ball_xy || !step_count || !reward || !done) return LMAZE_E_NULL;
     if (misaligned(ball_xy, 8) || misaligned(obs, 16) || misaligned(layout, 16)) return LMAZE_E_ALIGN;
     StepArgs a = make_args(params, layout, action, ball_xy, nullptr, step_count, reward, done, goal_count, obs, n);
+    if (bad_epoch_words(epoch_in_dev, epoch_out_dev)) return LMAZE_E_ALIGN;
     a.auto_reset = 1;
     a.seed = seed;
     a.epoch = epoch;
     a.env_base = env_base;
+    a.epoch_in = epoch_in_dev;
+    a.epoch_out = epoch_out_dev;
     return (int)launch_step(LMAZE_VARIANT_V0, true, a, params->layout_mode, (hipStream_t)stream);
 }
 
 int lmaze_step_v3_autoreset(const LmazeParams* params, const uint8_t* layout, const int32_t* action,
                             int32_t* ball_xy, int32_t* goal_xy, int32_t* step_count, float* reward,
                             uint8_t* done, int32_t* obs, int64_t n, uint64_t seed, uint64_t epoch,
-                            int64_t env_base, void* stream) {
+                            int64_t env_base, const uint64_t* epoch_in_dev, uint64_t* epoch_out_dev, void* stream) {
     int rc = check_params(params, n);
     if (rc) return rc;
     if (params->variant != LMAZE_VARIANT_V3) return LMAZE_E_VARIANT;
@@ -136,10 +141,13 @@ int lmaze_step_v3_autoreset(const LmazeParams* params, const uint8_t* layout, co
     if (misaligned(ball_xy, 8) || misaligned(goal_xy, 8) || misaligned(obs, 16) || misaligned(layout, 16))
         return LMAZE_E_ALIGN;
     StepArgs a = make_args(params, layout, action, ball_xy, goal_xy, step_count, reward, done, nullptr, obs, n);
+    if (bad_epoch_words(epoch_in_dev, epoch_out_dev)) return LMAZE_E_ALIGN;
     a.auto_reset = 1;
     a.seed = seed;
     a.epoch = epoch;
     a.env_base = env_base;
+    a.epoch_in = epoch_in_dev;
+    a.epoch_out = epoch_out_dev;
     a.goal_rw = reinterpret_cast<int2*>(goal_xy);
     return (int)launch_step(LMAZE_VARIANT_V3, true, a, params->layout_mode, (hipStream_t)stream);
 }
@@ -194,6 +202,13 @@ int lmaze_episode_stats(const uint8_t* done, const float* reward, const int32_t*
     if (n < 0 || n > ((int64_t)1 << 40)) return LMAZE_E_COUNT;
     if (misaligned(out4, 8)) return LMAZE_E_ALIGN;
     return (int)launch_episode_stats(done, reward, step_count, goal_count, reward_goal, n, out4, (hipStream_t)stream);
+}
+
+int lmaze_bandwidth_probe(const void* src, void* dst, int64_t bytes, void* stream) {
+    if (!dst) return LMAZE_E_NULL;
+    if (bytes < 0 || bytes > ((int64_t)1 << 40) || (bytes & 15)) return LMAZE_E_COUNT;
+    if (misaligned(dst, 16) || (src && misaligned(src, 16))) return LMAZE_E_ALIGN;
+    return (int)launch_probe(src, dst, bytes, (hipStream_t)stream);
 }
 
 int lmaze_render_expanded(const int32_t* obs, int32_t grid, int32_t expansion, const int32_t* channel_mask_host,

@@ -204,6 +204,33 @@ hipError_t launch_episode_stats(const uint8_t* done, const float* reward, const 
     return hipGetLastError();
 }
 
+// ---------------------------------------------------------------------------------------------------
+// measured ceilings of the box ("a measured fill/copy-kernel ceiling on the same box"):
+// ONE 16-byte access per thread in launch order, the pattern that reaches the highest write rate here.
+// ---------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(LMAZE_BLOCK) void probe_fill_kernel(int4* dst, int64_t n16) {
+    const int64_t i = (int64_t)blockIdx.x * LMAZE_BLOCK + threadIdx.x;
+    if (i < n16) dst[i] = make_int4((int)i, 1, 2, 3);
+}
+
+__global__ __launch_bounds__(LMAZE_BLOCK) void probe_copy_kernel(const int4* __restrict__ src, int4* __restrict__ dst,
+                                                                 int64_t n16) {
+    const int64_t i = (int64_t)blockIdx.x * LMAZE_BLOCK + threadIdx.x;
+    if (i < n16) dst[i] = src[i];
+}
+
+hipError_t launch_probe(const void* src, void* dst, int64_t bytes, hipStream_t s) {
+    const int64_t n16 = bytes / 16;
+    if (n16 == 0) return hipSuccess;
+    const int64_t blocks = (n16 + LMAZE_BLOCK - 1) / LMAZE_BLOCK;
+    if (src)
+        hipLaunchKernelGGL(probe_copy_kernel, dim3((unsigned)blocks), dim3(LMAZE_BLOCK), 0, s,
+                           static_cast<const int4*>(src), static_cast<int4*>(dst), n16);
+    else
+        hipLaunchKernelGGL(probe_fill_kernel, dim3((unsigned)blocks), dim3(LMAZE_BLOCK), 0, s, static_cast<int4*>(dst), n16);
+    return hipGetLastError();
+}
+
 hipError_t launch_expand(const ExpandArgs& a, hipStream_t s) {
     if (a.n == 0) return hipSuccess;
     const int S = a.grid * a.expansion;

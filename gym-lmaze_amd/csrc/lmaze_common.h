@@ -32,6 +32,10 @@ struct StepArgs {
     int32_t auto_reset;
     uint64_t seed, epoch;
     int64_t env_base;
+    // device-resident epoch (captured graphs): the launch draws with epoch + *epoch_in and its workgroup 0
+    // leaves *epoch_in + 1 in *epoch_out (a different word: the other workgroups still read epoch_in)
+    const uint64_t* epoch_in;
+    uint64_t* epoch_out;
     int2* goal_rw;           // v3 + auto_reset: the goal array, writable
     const uint8_t* mask;     // observe only: re-render just the envs with mask != 0 (null = all)
     int32_t launch_hint;     // LmazeParams.launch_hint (0 = library default policy)
@@ -61,9 +65,16 @@ struct ExpandArgs {
     int32_t mask[LMAZE_MAX_CHANNELS];
 };
 
+// device-resident epoch words of the *_autoreset entry points: 8-byte aligned, epoch_out only together with
+// epoch_in, and never the same word (the other workgroups still read epoch_in while workgroup 0 writes)
+inline bool bad_epoch_words(const uint64_t* in, const uint64_t* out) {
+    return ((((uintptr_t)in) | ((uintptr_t)out)) & 7) != 0 || (in && in == out) || (!in && out);
+}
+
 hipError_t launch_step(int variant, bool do_step, const StepArgs& a, int layout_mode, hipStream_t s);
 hipError_t launch_reset(int variant, const ResetArgs& a, int layout_mode, hipStream_t s);
 hipError_t launch_expand(const ExpandArgs& a, hipStream_t s);
+hipError_t launch_probe(const void* src, void* dst, int64_t bytes, hipStream_t s);
 hipError_t launch_episode_stats(const uint8_t* done, const float* reward, const int32_t* step_count,
                                 const int32_t* goal_count, float reward_goal, int64_t n, int64_t* out4, hipStream_t s);
 
@@ -154,6 +165,16 @@ __device__ __forceinline__ uint4 philox4x32_10(uint4 c, uint2 k) {
 }
 
 // the reset draw of one env: counter = (global env index, epoch), key = seed
+// epoch of this launch: the host's count plus the device-resident one, when the caller keeps one
+__device__ __forceinline__ uint64_t launch_epoch(uint64_t epoch, const uint64_t* epoch_in) {
+    return epoch_in ? epoch + *epoch_in : epoch;
+}
+
+// one thread of the launch hands the next launch its epoch (stream order makes it visible)
+__device__ __forceinline__ void pass_epoch_on(const uint64_t* epoch_in, uint64_t* epoch_out) {
+    if (epoch_in && epoch_out && blockIdx.x == 0 && threadIdx.x == 0) *epoch_out = *epoch_in + 1;
+}
+
 __device__ __forceinline__ uint4 env_draw(uint64_t seed, uint64_t epoch, int64_t env_global) {
     const uint64_t e = (uint64_t)env_global;
     return philox4x32_10(make_uint4((uint32_t)e, (uint32_t)(e >> 32), (uint32_t)epoch, (uint32_t)(epoch >> 32)),

@@ -31,6 +31,8 @@ struct FovealArgs {
     int32_t place;
     uint64_t seed, epoch;
     int64_t env_base;
+    const uint64_t* epoch_in;  // fused auto-reset from a captured graph: device-resident epoch (lmaze_common.h)
+    uint64_t* epoch_out;
     int32_t nt;             // non-temporal observation stores (set by the launcher)
     int32_t auto_reset;     // step: an env whose done flag is set on entry is reset first (v1, v2, v4)
 };
@@ -165,6 +167,7 @@ __global__ __launch_bounds__(LMAZE_BLOCK) void foveal_kernel(const FovealArgs a)
     const int64_t blockbase = (int64_t)blockIdx.x * EPB;
     const int nb = (int)min((int64_t)EPB, a.n - blockbase);
     if (tid == 0) any_skip = 0;
+    if (MODE == FM_STEP && AR) pass_epoch_on(a.epoch_in, a.epoch_out);
     for (int i = tid; i < L * CELLS; i += LMAZE_BLOCK) lays[i] = a.layouts[i];
     __syncthreads();
     for (int i = tid; i < L * G; i += LMAZE_BLOCK) {
@@ -366,7 +369,7 @@ __global__ __launch_bounds__(LMAZE_BLOCK) void foveal_kernel(const FovealArgs a)
             const bool fused = MODE == FM_STEP && AR && a.b.done[e] != 0;
             if ((MODE == FM_RESET && !r.skip) || fused) {              // reset(): v2:80-123, v4:95-163
                 if (a.place || fused) {
-                    const uint4 d = env_draw(a.seed, a.epoch, a.env_base + e);
+                    const uint4 d = env_draw(a.seed, launch_epoch(a.epoch, a.epoch_in), a.env_base + e);
                     const int lid_new = (int)__umulhi(d.z, (uint32_t)L);
                     if (V4) lid = lid_new;                             // v4:97 setGrid first
                     lid = clampi(lid, 0, L - 1);
@@ -759,6 +762,8 @@ static FovealArgs make_foveal_args(const LmazeFovealParams* p, const uint8_t* la
     a.seed = 0;
     a.epoch = 0;
     a.env_base = 0;
+    a.epoch_in = nullptr;
+    a.epoch_out = nullptr;
     a.nt = 0;
     a.auto_reset = 0;
     return a;
@@ -782,18 +787,21 @@ int lmaze_foveal_step(const LmazeFovealParams* params, const uint8_t* layouts, c
 
 int lmaze_foveal_step_autoreset(const LmazeFovealParams* params, const uint8_t* layouts, const int32_t* action,
                                 const LmazeFovealBuffers* bufs, int64_t n, uint64_t seed, uint64_t epoch,
-                                int64_t env_base, void* stream) {
+                                int64_t env_base, const uint64_t* epoch_in_dev, uint64_t* epoch_out_dev, void* stream) {
     int rc = check_foveal(params, layouts, bufs, n);
     if (rc) return rc;
     if (params->variant != LMAZE_VARIANT_V1 && params->variant != LMAZE_VARIANT_V2 && params->variant != LMAZE_VARIANT_V4)
         return LMAZE_E_VARIANT;
     if (!action) return LMAZE_E_NULL;
+    if (bad_epoch_words(epoch_in_dev, epoch_out_dev)) return LMAZE_E_ALIGN;
     FovealArgs a = make_foveal_args(params, layouts, bufs, n);
     a.action = action;
     a.auto_reset = 1;
     a.seed = seed;
     a.epoch = epoch;
     a.env_base = env_base;
+    a.epoch_in = epoch_in_dev;
+    a.epoch_out = epoch_out_dev;
     return (int)launch_foveal_mode<FM_STEP>(a, (hipStream_t)stream);
 }
 

@@ -71,7 +71,7 @@ __device__ __forceinline__ void env_phase1(const StepArgs& a, const uint8_t* lay
         float r_in = in.r;
         if (a.auto_reset && in.was_done) {  // reference reset(): placement + zeroed counters
             int bc, gc;
-            place_from_list<VARIANT>(spawn, spawn_count, env_draw(a.seed, a.epoch, a.env_base + e), bc, gc);
+            place_from_list<VARIANT>(spawn, spawn_count, env_draw(a.seed, launch_epoch(a.epoch, a.epoch_in), a.env_base + e), bc, gc);
             if (bc >= 0) b = make_int2(bc / G, bc % G);
             if (V3 && gc >= 0) {
                 g = make_int2(gc / G, gc % G);
@@ -130,6 +130,7 @@ __global__ __launch_bounds__(LMAZE_BLOCK) void step_shared_kernel(const StepArgs
     const int nb = (int)min((int64_t)EPB, a.n - blockbase);  // envs in this workgroup
     const bool masked = !DO_STEP && a.mask != nullptr;
     const bool autoreset = DO_STEP && a.auto_reset;
+    if (autoreset) pass_epoch_on(a.epoch_in, a.epoch_out);
 
     EnvIn in{};
     if (tid < nb) in = load_env<VARIANT, DO_STEP>(a, blockbase + tid);
@@ -260,6 +261,7 @@ __global__ __launch_bounds__(LMAZE_BLOCK) void step_perenv_kernel(const StepArgs
     const int R = nb * CELLS;  // layout bytes read == obs dwords written by this workgroup
     const bool autoreset = DO_STEP && a.auto_reset;
     const bool masked = !DO_STEP && a.mask != nullptr;
+    if (autoreset) pass_epoch_on(a.epoch_in, a.epoch_out);
 
     EnvIn in{};  // this lane's env, loaded while the layouts are still on their way
     if (tid < nb) in = load_env<VARIANT, DO_STEP>(a, blockbase + tid);
@@ -284,7 +286,7 @@ __global__ __launch_bounds__(LMAZE_BLOCK) void step_perenv_kernel(const StepArgs
         for (int le = tid >> 6; le < nb; le += LMAZE_BLOCK / 64) {
             if (!flag[le]) continue;
             int bc, gc;
-            wave_place<VARIANT>(tile + le * CELLS, G, CELLS, env_draw(a.seed, a.epoch, a.env_base + blockbase + le), lane,
+            wave_place<VARIANT>(tile + le * CELLS, G, CELLS, env_draw(a.seed, launch_epoch(a.epoch, a.epoch_in), a.env_base + blockbase + le), lane,
                                 bc, gc);
             if (lane == 0) { newball[le] = bc; newgoal[le] = gc; }
         }
@@ -400,6 +402,7 @@ __global__ __launch_bounds__(LMAZE_BLOCK) void step_perenv_wave_kernel(const Ste
     const int64_t wave = (int64_t)blockIdx.x * (LMAZE_BLOCK / 64) + (threadIdx.x >> 6);
     const bool autoreset = DO_STEP && a.auto_reset;
     const bool masked = !DO_STEP && a.mask != nullptr;
+    if (autoreset) pass_epoch_on(a.epoch_in, a.epoch_out);
 
 #pragma unroll 1
     for (int k = 0; k < EPW; ++k) {
@@ -420,7 +423,7 @@ __global__ __launch_bounds__(LMAZE_BLOCK) void step_perenv_wave_kernel(const Ste
             float r_in = V3 ? 0.0f : a.reward[e];
             if (autoreset && a.done[e]) {  // re-place from the layout registers (wave-uniform branch)
                 int bc, gc;
-                wave_place_regs<VARIANT, G, NJ>(w, env_draw(a.seed, a.epoch, a.env_base + e), lane, bc, gc);
+                wave_place_regs<VARIANT, G, NJ>(w, env_draw(a.seed, launch_epoch(a.epoch, a.epoch_in), a.env_base + e), lane, bc, gc);
                 if (bc >= 0) b = make_int2(bc / G, bc % G);
                 if (V3 && gc >= 0) {
                     g = make_int2(gc / G, gc % G);

@@ -48,6 +48,7 @@ class LmazeFovealVecEnv(object):
         self.channels = spec["channels"]
         self.expansion = spec["expansion"]
         self.seed, self.env_base, self._epoch = int(seed), int(env_base), 0
+        self._epoch_words = None     # device-resident epoch pair (captured auto-reset steps)
         tabs = [L.to_codes(t) for t in (layouts if layouts is not None else spec["layouts"])]
         G = tabs[0].shape[0]
         pad = 2 if variant == "v1" else 2   # the 5x5 window must stay inside the array
@@ -151,20 +152,37 @@ class LmazeFovealVecEnv(object):
         return m, m.data_ptr()
 
     # ------------------------------------------------------------------ the path
-    def step(self, actions, auto_reset=False):
+    def begin_replay(self, n_launches):
+        """Before replaying a captured sequence of n_launches auto-reset steps (step(..., epoch_slot=t)):
+        hand the host's epoch count to the device word launch 0 reads and reserve n_launches epochs."""
+        if self._epoch_words is None:
+            self._epoch_words = torch.zeros(2, dtype=torch.int64, device=self.device)
+        self._epoch_words[0:1].fill_(self._epoch)
+        self._epoch += int(n_launches)
+
+    def step(self, actions, auto_reset=False, epoch_slot=None):
         """v1: ids 0..3 (else no move); v2/v4: 0..24 = 5*row+col of the target cell in the window.
         Returns (obs, reward, done, actions); v1's second stream is in foveal_reward / foveal_done.
         auto_reset=True (v1, v2, v4) first resets the envs whose done flag is still set from the previous
-        step, fused into the same kernel: bit-identical to reset(mask=done) + step(actions)."""
+        step, fused into the same kernel: bit-identical to reset(mask=done) + step(actions).
+        epoch_slot=t (under hipGraph capture, t = index of the launch in the captured sequence) keeps the
+        reset epoch on the device so that replays draw fresh placements; call begin_replay(T) before each."""
         a = self._as_i32(actions, self.num_envs)
         with self._guard():
             if auto_reset:
                 if self._two_level:
                     raise ValueError("auto_reset is not defined for v5/v6 (episodes restart through planner_step)")
+                if epoch_slot is None:
+                    epoch, e_in, e_out = self._epoch, None, None
+                    self._epoch += 1
+                else:
+                    if self._epoch_words is None:
+                        self._epoch_words = torch.zeros(2, dtype=torch.int64, device=self.device)
+                    base, t = self._epoch_words.data_ptr(), int(epoch_slot)
+                    epoch, e_in, e_out = 0, base + 8 * (t & 1), base + 8 * ((t + 1) & 1)
                 rc = _abi.lib.lmaze_foveal_step_autoreset(self._pp, self._p_layouts, a.data_ptr(), self._pb,
-                                                          self.num_envs, self.seed & (2 ** 64 - 1), self._epoch,
-                                                          self.env_base, self._stream())
-                self._epoch += 1
+                                                          self.num_envs, self.seed & (2 ** 64 - 1), epoch,
+                                                          self.env_base, e_in, e_out, self._stream())
             else:
                 rc = _abi.lib.lmaze_foveal_step(self._pp, self._p_layouts, a.data_ptr(), self._pb, self.num_envs,
                                                 self._stream())

@@ -73,6 +73,7 @@ class LmazeVecEnv(object):
         self.seed = int(seed)
         self.env_base = int(env_base)
         self._epoch = 0
+        self._epoch_words = None        # device-resident epoch pair, allocated by the first captured rollout
         self._is_v3 = variant == "v3"
 
         N = self.num_envs
@@ -185,24 +186,47 @@ class LmazeVecEnv(object):
             self._launch_step(a.data_ptr(), self._p_obs if render else None, auto_reset)
         return self.obs, self.reward, self.done, actions
 
-    def step_raw(self, action_ptr, auto_reset=False):
+    def step_raw(self, action_ptr, auto_reset=False, epoch_slot=None):
         """step() on a raw device pointer to int32[N] actions (no tensor handling): for
-        rollouts over a pre-generated [T,N] action tensor, e.g. under graph capture."""
-        self._launch_step(action_ptr, self._p_obs, auto_reset)
+        rollouts over a pre-generated [T,N] action tensor, e.g. under graph capture.  epoch_slot
+        (auto_reset under capture): index t of the launch within the captured sequence -- the reset epoch
+        then lives on the device (see begin_replay)."""
+        self._launch_step(action_ptr, self._p_obs, auto_reset, epoch_slot)
 
-    def _launch_step(self, action_ptr, obs_ptr, auto_reset):
+    def _epoch_word_ptrs(self, slot):
+        """Device addresses (in, out) of the two alternating epoch words for launch `slot` of a capture."""
+        if self._epoch_words is None:
+            self._epoch_words = torch.zeros(2, dtype=torch.int64, device=self.device)
+        base = self._epoch_words.data_ptr()
+        return base + 8 * (slot & 1), base + 8 * ((slot + 1) & 1)
+
+    def begin_replay(self, n_launches):
+        """Call before replaying a captured sequence of n_launches auto-reset steps: hands the host's epoch
+        count to the device word the first launch reads (one tiny fill on the current stream, no sync) and
+        reserves n_launches epochs, so every replay -- and every eager call in between -- draws placements
+        no earlier launch has used."""
+        self._epoch_word_ptrs(0)
+        self._epoch_words[0:1].fill_(self._epoch)
+        self._epoch += int(n_launches)
+
+    def _launch_step(self, action_ptr, obs_ptr, auto_reset, epoch_slot=None):
         lib, N, st = _abi.lib, self.num_envs, self._stream()
         if auto_reset:
-            seed, epoch = self.seed & (2 ** 64 - 1), self._epoch
-            self._epoch += 1
+            seed = self.seed & (2 ** 64 - 1)
+            if epoch_slot is None:
+                epoch, e_in, e_out = self._epoch, None, None
+                self._epoch += 1
+            else:           # the count is on the device: frozen host arguments stay valid for every replay
+                epoch = 0
+                e_in, e_out = self._epoch_word_ptrs(int(epoch_slot))
             if self._is_v3:
                 rc = lib.lmaze_step_v3_autoreset(self._pp, self._p_layout, action_ptr, self._p_ball, self._p_goal,
                                                  self._p_step, self._p_reward, self._p_done, obs_ptr, N,
-                                                 seed, epoch, self.env_base, st)
+                                                 seed, epoch, self.env_base, e_in, e_out, st)
             else:
                 rc = lib.lmaze_step_v0_autoreset(self._pp, self._p_layout, action_ptr, self._p_ball, self._p_step,
                                                  self._p_reward, self._p_done, self._p_gc, obs_ptr, N,
-                                                 seed, epoch, self.env_base, st)
+                                                 seed, epoch, self.env_base, e_in, e_out, st)
         elif self._is_v3:
             rc = lib.lmaze_step_v3(self._pp, self._p_layout, action_ptr, self._p_ball, self._p_goal,
                                    self._p_step, self._p_reward, self._p_done, obs_ptr, N, st)
@@ -240,17 +264,18 @@ class LmazeVecEnv(object):
         self.observe()
         return timings
 
-    def rollout(self, actions, auto_reset=True):
+    def rollout(self, actions, auto_reset=True, device_epoch=False):
         """T steps over a device tensor int32[T,N] of actions, one kernel per step, no host
-        sync (capture it into a hipGraph with torch.cuda.graph for launch-bound batch sizes).
-        Returns the final (obs, reward, done)."""
+        sync (capture_rollout() records it into a hipGraph for launch-bound batch sizes).
+        device_epoch: keep the reset epoch on the device (what capture_rollout uses; bit-identical to the
+        host-counted epochs when begin_replay(T) precedes it).  Returns the final (obs, reward, done)."""
         if not (isinstance(actions, torch.Tensor) and actions.dtype == torch.int32 and actions.dim() == 2
                 and actions.shape[1] == self.num_envs and actions.device == self.device and actions.is_contiguous()):
             raise ValueError("rollout() wants a contiguous int32[T,N] tensor on %s" % (self.device,))
         base, stride = actions.data_ptr(), self.num_envs * 4
         with self._guard():
             for t in range(actions.shape[0]):
-                self._launch_step(base + t * stride, self._p_obs, auto_reset)
+                self._launch_step(base + t * stride, self._p_obs, auto_reset, t if device_epoch else None)
         return self.obs, self.reward, self.done
 
     def observe(self):
@@ -308,18 +333,22 @@ class LmazeVecEnv(object):
 
     def capture_rollout(self, actions, auto_reset=False):
         """Capture the T = actions.shape[0] launches of rollout(actions) into ONE hipGraph and return it
-        (torch.cuda.CUDAGraph; call .replay()).  For launch-bound batch sizes (65 536 x 8x8 is 6 us per
+        (a RolloutGraph; call .replay()).  For launch-bound batch sizes (65 536 x 8x8 is 6 us per
         step, a third of it launch gap).  The launches allocate nothing and never synchronise, so they are
-        capturable as they are.  With auto_reset the reset epochs are baked into the graph: every replay
-        re-uses the same placement draws."""
+        capturable as they are.  With auto_reset the reset epoch is a device word the launches hand on to
+        each other (lmaze_step_*_autoreset, epoch_in_dev / epoch_out_dev), so every replay draws fresh
+        placements, and exactly those the same steps launched eagerly would draw."""
+        T = int(actions.shape[0])
+        if auto_reset:
+            self._epoch_word_ptrs(0)            # allocate before capture
         side = torch.cuda.Stream(device=self.device)
         side.wait_stream(torch.cuda.current_stream(self.device))
         graph = torch.cuda.CUDAGraph()
         with torch.cuda.stream(side):
             with torch.cuda.graph(graph, stream=side):
-                self.rollout(actions, auto_reset=auto_reset)
+                self.rollout(actions, auto_reset=auto_reset, device_epoch=auto_reset)
         torch.cuda.current_stream(self.device).wait_stream(side)
-        return graph
+        return RolloutGraph(self, graph, T, auto_reset)
 
     def episode_stats(self, all_ranks=False):
         """Counters over the batch, off the step path: {"done", "goal_rewards", "done_steps", "goal_count"}.
@@ -361,6 +390,18 @@ class LmazeVecEnv(object):
         return dict(ball_xy=v(self.ball_xy, np.int32, (N, 2)), goal_xy=v(self.goal_xy, np.int32, (N, 2)),
                     step_count=v(self.step_count, np.int32, (N,)), reward=v(self.reward, np.float32, (N,)),
                     goal_count=v(self.goal_count, np.int32, (N,)), done=v(self._done_u8, np.uint8, (N,)))
+
+
+class RolloutGraph:
+    """A captured rollout (LmazeVecEnv.capture_rollout): replay() relaunches its T steps in one go."""
+
+    def __init__(self, env, graph, n_launches, auto_reset):
+        self.env, self.graph, self.n_launches, self.auto_reset = env, graph, n_launches, auto_reset
+
+    def replay(self):
+        if self.auto_reset:
+            self.env.begin_replay(self.n_launches)
+        self.graph.replay()
 
 
 def _validate_on_device(lay, need_goal=True):

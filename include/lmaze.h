@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define LMAZE_ABI_VERSION 1
+#define LMAZE_ABI_VERSION 2
 
 /* which reference class the transition rules come from */
 enum {
@@ -153,16 +153,25 @@ int lmaze_reset(const LmazeParams* params, const uint8_t* layout, const uint8_t*
  * extra HBM traffic.  Results are bit-identical to calling lmaze_reset then lmaze_step_*.
  * The caller advances `epoch` every call so successive episodes draw fresh placements.
  * goal_xy (v3) is read and, for reset envs, rewritten.
+ *
+ * Device-resident epoch (both nullable; for launches captured in a hipGraph, whose host
+ * arguments are frozen): with epoch_in_dev != NULL the launch draws with epoch + *epoch_in_dev,
+ * and with epoch_out_dev != NULL too its first workgroup stores *epoch_in_dev + 1 there.  The two
+ * must be DIFFERENT 8-byte-aligned device words (the rest of the grid still reads the first);
+ * a captured rollout alternates them launch by launch, so each replay continues the count and
+ * draws fresh placements.  LMAZE_E_ALIGN if they alias, are misaligned, or only _out is given.
  */
 int lmaze_step_v0_autoreset(const LmazeParams* params, const uint8_t* layout, const int32_t* action,
                             int32_t* ball_xy, int32_t* step_count, float* reward, uint8_t* done,
                             int32_t* goal_count, int32_t* obs, int64_t n, uint64_t seed,
-                            uint64_t epoch, int64_t env_base, void* stream);
+                            uint64_t epoch, int64_t env_base, const uint64_t* epoch_in_dev,
+                            uint64_t* epoch_out_dev, void* stream);
 
 int lmaze_step_v3_autoreset(const LmazeParams* params, const uint8_t* layout, const int32_t* action,
                             int32_t* ball_xy, int32_t* goal_xy, int32_t* step_count, float* reward,
                             uint8_t* done, int32_t* obs, int64_t n, uint64_t seed, uint64_t epoch,
-                            int64_t env_base, void* stream);
+                            int64_t env_base, const uint64_t* epoch_in_dev, uint64_t* epoch_out_dev,
+                            void* stream);
 
 /*
  * Reference-layout observation: replaces the 5-deep upsample loop (v0:217-234,
@@ -186,6 +195,15 @@ int lmaze_render_expanded(const int32_t* obs, int32_t grid, int32_t expansion,
  */
 int lmaze_episode_stats(const uint8_t* done, const float* reward, const int32_t* step_count,
                         const int32_t* goal_count, float reward_goal, int64_t n, int64_t* out4, void* stream);
+
+/*
+ * Measured ceiling of the device this library runs on (SURVEY 8(d) asks for a measured fill / copy
+ * ceiling beside the 8 TB/s figure): src == NULL fills `bytes` of dst with one 16-byte store per
+ * thread in launch order; otherwise copies src -> dst the same way.  bytes % 16 == 0, both pointers
+ * 16-byte aligned.  bench.py times it with events on the launch stream and reports
+ * roofline.measured_ceiling; nothing on the step path calls it.  No reference counterpart.
+ */
+int lmaze_bandwidth_probe(const void* src, void* dst, int64_t bytes, void* stream);
 
 /* ====================================================================================== */
 /* Foveal variants: the agent sees a 5x5 window (a8 crop, a9 frame history of SURVEY 8a).  */
@@ -258,11 +276,12 @@ int lmaze_foveal_step(const LmazeFovealParams* params, const uint8_t* layouts, c
  * exactly as lmaze_foveal_reset(mask = done, place = 1, seed, epoch, env_base) would, then takes this step's
  * action -- bit-identical to the two calls, one launch.  (A masked reset launch per step costs +78 % on v2
  * and +39 % on v4 at 1M envs; fused it is free.)  v5/v6 episodes restart through plannerStep and are not
- * covered.
+ * covered.  epoch_in_dev / epoch_out_dev: the device-resident epoch, as for lmaze_step_v0_autoreset.
  */
 int lmaze_foveal_step_autoreset(const LmazeFovealParams* params, const uint8_t* layouts, const int32_t* action,
                                 const LmazeFovealBuffers* bufs, int64_t n, uint64_t seed, uint64_t epoch,
-                                int64_t env_base, void* stream);
+                                int64_t env_base, const uint64_t* epoch_in_dev, uint64_t* epoch_out_dev,
+                                void* stream);
 
 /*
  * reset() of the envs with mask[i] != 0 (NULL = all): step_count = 0, rewards = -0.0, done

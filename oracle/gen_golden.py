@@ -545,7 +545,59 @@ def gen_v6():
     save_events("v6_seed2", rollout_v56("v6", 400, seed=2, safe_goals=True))
 
 
-GENERATORS = {"v0": gen_v0, "v3": gen_v3, "v1": gen_v1, "v2": gen_v2, "v4": gen_v4, "v5": gen_v5, "v6": gen_v6}
+# ----------------------------------------------------------------------------------------
+# the placement switches the reference exposes as plain attributes (RANDOM_BALL / RANDOM_GOAL)
+# ----------------------------------------------------------------------------------------
+def rollout_flags(variant, actions, seed, random_ball, random_goal=None):
+    """v0 / v3 / v2 with the switches flipped after construction: start cell 'S' (lmaze_env.py:82-89),
+    goal at the 'X' cell (lmaze_env_v3.py:116-117 keeps it; lmaze_env_v2.py:284-286 looks it up)."""
+    random.seed(seed)
+    np.random.seed(seed)
+    env = ref_loader.make(variant)
+    env.RANDOM_BALL = random_ball
+    if random_goal is not None:
+        env.RANDOM_GOAL = random_goal
+    E = env.expansionRatio
+    T = len(actions)
+    rec = dict(E=np.int32(E), seed=np.int64(seed), random_ball=np.uint8(random_ball),
+               random_goal=np.uint8(1 if random_goal is None else random_goal),
+               actions=np.asarray(actions, dtype=np.int32), reset_before=np.zeros(T, np.uint8),
+               ball_before=np.zeros((T, 2), np.int32), goal_before=np.zeros((T, 2), np.int32),
+               reward=np.zeros(T, np.float64), done=np.zeros(T, np.uint8), ball=np.zeros((T, 2), np.int32),
+               obs_hash=np.zeros(T, np.uint64))
+    reset_hash = []
+    need_reset = True
+    for t in range(T):
+        if need_reset:
+            o = env.reset()
+            reset_hash.append(obs_hash(np.ascontiguousarray(o)))
+            rec["reset_before"][t] = 1
+            need_reset = False
+        rec["ball_before"][t] = (env.ball_x0, env.ball_y0)
+        rec["goal_before"][t] = (env.goal_x, env.goal_y)
+        a = int(actions[t])
+        arg = (str(a) if 0 <= a <= 3 else a) if variant == "v3" else a
+        o, r, d, _ = env.step(arg)
+        rec["reward"][t] = r
+        rec["done"][t] = d
+        rec["ball"][t] = (env.ball_x0, env.ball_y0)
+        rec["obs_hash"][t] = obs_hash(np.ascontiguousarray(o))
+        need_reset = bool(d)
+    rec["reset_hash"] = np.array(reset_hash, np.uint64)
+    return rec
+
+
+def gen_flags():
+    a4 = np.random.RandomState(71).randint(0, 4, 260).astype(np.int32)
+    save("flags_v0_fixed_start", rollout_flags("v0", a4, 0, random_ball=False))
+    save("flags_v3_fixed_start_goal", rollout_flags("v3", a4, 1, random_ball=False, random_goal=False))
+    save("flags_v3_fixed_goal", rollout_flags("v3", a4, 2, random_ball=True, random_goal=False))
+    save("flags_v2_fixed_goal", rollout_flags("v2", foveal_actions(72, 160), 3, random_ball=True, random_goal=False))
+    save("flags_v2_fixed_start", rollout_flags("v2", foveal_actions(73, 160), 4, random_ball=False, random_goal=True))
+
+
+GENERATORS = {"v0": gen_v0, "v3": gen_v3, "v1": gen_v1, "v2": gen_v2, "v4": gen_v4, "v5": gen_v5, "v6": gen_v6,
+              "flags": gen_flags}
 
 if __name__ == "__main__":
     which = sys.argv[1:] or sorted(GENERATORS)

@@ -193,3 +193,81 @@ def test_episode_stats_match_numpy():
     v3 = PKG.LmazeVecEnv(5000, variant="v3", seed=1)
     v3.step(torch.randint(0, 4, (5000,), dtype=torch.int32, device="cuda"))
     assert v3.episode_stats()["goal_count"] == 0 and v3.episode_stats()["done"] == int(v3.done.sum().item())
+
+
+@pytest.mark.parametrize("variant,shared,G", [("v0", True, 8), ("v3", True, 11), ("v0", False, 12), ("v3", False, 16),
+                                              ("v0", False, 32)])
+def test_captured_autoreset_rollout_draws_fresh_placements(variant, shared, G):
+    """A captured auto-reset rollout keeps its reset epoch in a device word the launches hand on to each
+    other: replays (odd T, so the two words swap roles between replays) and eager steps in between are
+    bit-identical to the same steps launched eagerly, i.e. no replay re-uses an earlier replay's draws."""
+    from helpers import bordered_random_layouts
+    N, T = 3000, 7
+    kw = dict(variant=variant, seed=13, step_limit=4, env_base=77)      # short episodes: resets every replay
+    if shared:
+        lay = bordered_random_layouts(1, G, 40 + G)[0]
+        eager, graphed = PKG.LmazeVecEnv(N, layout=lay, **kw), PKG.LmazeVecEnv(N, layout=lay, **kw)
+    else:
+        lay = bordered_random_layouts(N, G, 40 + G)
+        eager, graphed = PKG.LmazeVecEnv(N, per_env_layouts=lay, **kw), PKG.LmazeVecEnv(N, per_env_layouts=lay, **kw)
+    acts = torch.randint(0, 4, (T, N), dtype=torch.int32, device="cuda")
+    extra = torch.randint(0, 4, (N,), dtype=torch.int32, device="cuda")
+    g = graphed.capture_rollout(acts, auto_reset=True)
+    assert int(graphed.step_count.max().item()) == 0                   # capture runs nothing
+
+    def same(tag):
+        torch.cuda.synchronize()
+        he, hg = eager.host_state(), graphed.host_state()
+        for k in he:
+            assert (he[k].view(np.uint8) == hg[k].view(np.uint8)).all(), (k, tag)
+        assert (eager.obs == graphed.obs).all(), tag
+
+    starts = []
+    for rep in range(3):
+        g.replay()
+        eager.rollout(acts, auto_reset=True)
+        same(("replay", rep))
+        starts.append(_np(graphed.ball_xy).copy())
+        if rep == 1:                                                   # an eager launch between two replays
+            graphed.step(extra, auto_reset=True)
+            eager.step(extra, auto_reset=True)
+            same("eager step in between")
+    assert not (starts[0] == starts[1]).all() and not (starts[1] == starts[2]).all()
+    # the ABI refuses aliased or half-given epoch words
+    abi = importlib.import_module("gym-lmaze_amd._abi")
+    w = torch.zeros(2, dtype=torch.int64, device="cuda")
+    st = torch.cuda.current_stream().cuda_stream
+    args = (eager._pp, eager._p_layout, extra.data_ptr(), eager._p_ball)
+    tail = (eager._p_step, eager._p_reward, eager._p_done)
+    if variant == "v3":
+        call = lambda i, o: abi.lib.lmaze_step_v3_autoreset(*args, eager._p_goal, *tail, eager._p_obs, N, 1, 0, 0, i, o, st)
+    else:
+        call = lambda i, o: abi.lib.lmaze_step_v0_autoreset(*args, *tail, eager._p_gc, eager._p_obs, N, 1, 0, 0, i, o, st)
+    assert call(w.data_ptr(), w.data_ptr()) == -6 and call(None, w.data_ptr()) == -6 and call(w.data_ptr() + 4, None) == -6
+
+
+@pytest.mark.parametrize("variant", ["v2", "v4"])
+def test_foveal_captured_autoreset_steps(variant):
+    N, T = 2000, 29                                                    # 3 replays > one 51-step episode
+    eager = PKG.LmazeFovealVecEnv(N, variant=variant, seed=3)
+    graphed = PKG.LmazeFovealVecEnv(N, variant=variant, seed=3)
+    acts = torch.randint(0, 25, (T, N), dtype=torch.int32, device="cuda")
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    graph = torch.cuda.CUDAGraph()
+    graphed.begin_replay(0)                                            # allocate the epoch words before capture
+    with torch.cuda.stream(side):
+        with torch.cuda.graph(graph, stream=side):
+            for t in range(T):
+                graphed.step(acts[t], auto_reset=True, epoch_slot=t)
+    torch.cuda.current_stream().wait_stream(side)
+    for rep in range(3):
+        graphed.begin_replay(T)
+        graph.replay()
+        for t in range(T):
+            eager.step(acts[t], auto_reset=True)
+        torch.cuda.synchronize()
+        he, hg = eager.host_state(), graphed.host_state()
+        for k in he:
+            assert (he[k].view(np.uint8) == hg[k].view(np.uint8)).all(), (k, rep)
+        assert (eager.obs.view(torch.int32) == graphed.obs.view(torch.int32)).all(), rep
