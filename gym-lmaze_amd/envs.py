@@ -20,6 +20,7 @@ import numpy as np
 import torch
 
 from . import layouts as L
+from ._staging import HostStaging
 from .compat import Box, Discrete, Env
 from .vec_env import LmazeVecEnv
 
@@ -47,6 +48,7 @@ class _LmazeBase(Env):
         self._grid_chars = L.to_char_grid(layout) if layout is not None else None
         self._expansion = expansion
         self._core = None
+        self._stage = None
         self._dirty = True
         self._host = None
 
@@ -58,6 +60,7 @@ class _LmazeBase(Env):
             self._core = LmazeVecEnv(self.num_envs, per_env_layouts=self._per_env_layouts, **kw)
         else:
             self._core = LmazeVecEnv(self.num_envs, layout=self._grid_chars, **kw)
+        self._stage = HostStaging(self._core.device) if self._single else None
         self._dirty = False
 
     def _step_limit(self):
@@ -93,8 +96,23 @@ class _LmazeBase(Env):
 
     # ------------------------------------------------------------------ host mirror (single env)
     def _sync_host(self):
-        self._host = self._core.host_state()
+        if self._stage is not None:
+            self._host = self._core.host_state(raw=self._stage.fetch(state=self._core._state)["state"].copy())
+        else:
+            self._host = self._core.host_state()
         return self._host
+
+    def _step_single(self, action):
+        """N = 1: upload the action, step, render xE, and bring observation + scalars back with one sync.
+        Returns (page-locked view of the (C,GE,GE) observation or None in compact mode, host scalars)."""
+        core, stage = self._core, self._stage
+        core.step(stage.action(action))
+        if self.obs_mode == "expanded":
+            got = stage.fetch(obs=core.expanded()[0], state=core._state)
+        else:
+            got = stage.fetch(state=core._state)
+        self._host = core.host_state(raw=got["state"].copy())
+        return got.get("obs"), self._host
 
     def _scalar(self, key, idx=None):
         h = self._host if self._host is not None else self._sync_host()
@@ -151,7 +169,7 @@ class _LmazeBase(Env):
         full = self._core.expanded()
         if not self._single:
             return full
-        return full[0].cpu().numpy()  # a fresh array per call, like lmaze_env.py:217
+        return self._stage.fetch(obs=full[0])["obs"].copy()  # a fresh array per call, like lmaze_env.py:217
 
     @property
     def core(self):
@@ -240,10 +258,8 @@ class LmazeEnv(_LmazeBase):
         core = self._core
         if self._single:
             a = int(msg)                                     # lmaze_env.py:148
-            act = torch.tensor([a if -2 ** 31 <= a < 2 ** 31 else _NOOP_ACTION], dtype=torch.int32)
-            core.step(act)
-            obs = self._obs_out(fresh=True)
-            h = self._sync_host()
+            view, h = self._step_single(a if -2 ** 31 <= a < 2 ** 31 else _NOOP_ACTION)
+            obs = view.copy() if view is not None else core.obs      # a fresh array per call (lmaze_env.py:217)
             return obs, self._reward_to_python(h["reward"][0]), bool(h["done"][0]), a
         core.step(msg)
         self._host = None
@@ -320,9 +336,10 @@ class LmazeEnv_v3(_LmazeBase):
         o = self._core.obs[0].cpu().numpy()
         return np.stack([((o & m) != 0).astype(np.float32) for m in self._core.channel_mask])
 
-    def _single_obs(self):
+    def _single_obs(self, arr=None):
         """v3 hands out one reused buffer (lmaze_env_v3.py:122,206,400)."""
-        arr = self._core.expanded()[0].cpu().numpy()
+        if arr is None:
+            arr = self._stage.fetch(obs=self._core.expanded()[0])["obs"]
         if self.retStateExpanded is None or self.retStateExpanded.shape != arr.shape:
             self.retStateExpanded = np.zeros(arr.shape, dtype=np.float32)
         np.copyto(self.retStateExpanded, arr)
@@ -371,10 +388,8 @@ class LmazeEnv_v3(_LmazeBase):
     def step(self, goal):
         core = self._core
         if self._single:
-            act = torch.tensor([_decode_v3_action(goal)], dtype=torch.int32)
-            core.step(act)
-            obs = self._single_obs() if self.obs_mode == "expanded" else core.obs
-            h = self._sync_host()
+            view, h = self._step_single(_decode_v3_action(goal))
+            obs = self._single_obs(view) if view is not None else core.obs
             return obs, self._reward_to_python(h["reward"][0]), bool(h["done"][0]), goal
         core.step(goal)   # batched: int32 ids, 0..3 move, anything else is the no-op
         self._host = None

@@ -262,8 +262,10 @@ class LmazeFovealVecEnv(object):
         _abi.check("lmaze_expand_planes", rc)
         return out
 
-    def host_state(self):
-        h = self._state.cpu().numpy()
+    def host_state(self, raw=None):
+        """Every per-env scalar on the host (numpy views of one copy of the state block; raw = that block
+        already fetched by the caller)."""
+        h = self._state.cpu().numpy() if raw is None else raw
         base = self._state.data_ptr()
         out = {}
         for name, t, dt in (("ball_xy", self.ball_xy, np.int32), ("goal_xy", self.goal_xy, np.int32),

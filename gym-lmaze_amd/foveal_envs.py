@@ -19,6 +19,7 @@ import random
 import numpy as np
 
 from . import layouts as L
+from ._staging import HostStaging
 from .compat import Box, Discrete, Env
 from .foveal_env import LmazeFovealVecEnv
 
@@ -39,6 +40,7 @@ class _FovealBase(Env):
             raise ValueError("obs_mode must be 'expanded' or 'compact'")
         self._core = LmazeFovealVecEnv(self.num_envs, variant=self._variant, device=device,
                                        seed=0 if seed is None else int(seed), reset=False)
+        self._stage = HostStaging(self._core.device) if self._single else None
         self._host = None
 
     @property
@@ -46,8 +48,32 @@ class _FovealBase(Env):
         return self._core
 
     def _sync(self):
-        self._host = self._core.host_state()
+        if self._stage is not None:
+            self._host = self._core.host_state(raw=self._stage.fetch(state=self._core._state)["state"].copy())
+        else:
+            self._host = self._core.host_state()
         return self._host
+
+    def _step_single(self, action, local=False):
+        """N = 1: upload the action, step, render x7, and bring the observation(s) + scalars back with one
+        sync.  Returns ({"obs": view, "loc": view (v5/v6)}, host scalars); views are page-locked mirrors."""
+        core, stage = self._core, self._stage
+        core.step(stage.action(action))
+        want = {"state": core._state}
+        if self.obs_mode == "expanded":
+            want["obs"] = core.expanded()[0]
+            if local:
+                want["loc"] = core.expanded_local()[0]
+        got = stage.fetch(**want)
+        self._host = core.host_state(raw=got["state"].copy())
+        return got, self._host
+
+    def _reused(self, arr):
+        """the reference's one shared output buffer (v2:66,123,223; v4:66,163,270)"""
+        if getattr(self, "retStateExpanded", None) is None or self.retStateExpanded.shape != arr.shape:
+            self.retStateExpanded = np.zeros(arr.shape, dtype=np.float32)
+        np.copyto(self.retStateExpanded, arr)
+        return self.retStateExpanded
 
     def _h(self, key):
         return (self._host if self._host is not None else self._sync())[key][0]
@@ -70,13 +96,8 @@ class _FovealBase(Env):
 
     def _obs_np(self, reuse):
         """single env, expanded mode: numpy (C,35,35); `reuse` = the reference's one shared buffer"""
-        arr = self._core.expanded()[0].cpu().numpy()
-        if not reuse:
-            return arr
-        if getattr(self, "retStateExpanded", None) is None or self.retStateExpanded.shape != arr.shape:
-            self.retStateExpanded = np.zeros(arr.shape, dtype=np.float32)
-        np.copyto(self.retStateExpanded, arr)
-        return self.retStateExpanded
+        arr = self._stage.fetch(obs=self._core.expanded()[0])["obs"]
+        return self._reused(arr) if reuse else arr.copy()
 
     def render(self, mode='human', close=False):
         if mode == 'human':
@@ -144,9 +165,8 @@ class LmazeEnv_v1(_FovealBase):
         core = self._core
         if self._single:
             a = next((k for k in range(4) if msg == k), -1)  # v1:126-133 compares, never casts
-            core.step(np.array([a], np.int32))
-            obs = self._out()
-            h = self._sync()
+            got, h = self._step_single(a)
+            obs = got["obs"].copy() if "obs" in got else core.obs    # a fresh array per call (v1:258)
             return (obs, self._reward_py(h["reward"][0]), self._reward_py(h["foveal_reward"][0]),
                     bool(h["foveal_done"][0]), bool(h["done"][0]), msg)
         core.step(msg)
@@ -255,9 +275,8 @@ class _TeleportBase(_FovealBase):
                 raise IndexError("index %d is out of bounds for the 5x5 action plane (lmaze_env_v2.py:135-136)" % g)
             bx, by = self.ball_x0, self.ball_y0
             self._fgoal = (bx + g // 5 - 2, by + g % 5 - 2)  # v2:151-152
-            core.step(np.array([g], np.int32))
-            obs = self._out()
-            h = self._sync()
+            got, h = self._step_single(g)
+            obs = self._reused(got["obs"]) if "obs" in got else core.obs
             return obs, self._reward_py(h["reward"][0]), bool(h["done"][0]), g
         core.step(goal)
         self._host = None
@@ -361,12 +380,16 @@ class LmazeEnv_v5(_TeleportBase):
     def _fov(self):
         if self.obs_mode == "compact":
             return self._core.obs
-        return self._core.expanded()[0].cpu().numpy() if self._single else self._core.expanded()   # fresh array, v5:308
+        if self._single:
+            return self._stage.fetch(obs=self._core.expanded()[0])["obs"].copy()              # fresh array, v5:308
+        return self._core.expanded()
 
     def _loc(self):
         if self.obs_mode == "compact":
             return self._core.obs_local
-        return self._core.expanded_local()[0].cpu().numpy() if self._single else self._core.expanded_local()
+        if self._single:
+            return self._stage.fetch(loc=self._core.expanded_local()[0])["loc"].copy()
+        return self._core.expanded_local()
 
     def reset(self, mask=None):
         if self._single:
@@ -394,15 +417,16 @@ class LmazeEnv_v5(_TeleportBase):
         core = self._core
         if self._single:
             a = int(goal)
-            core.step(np.array([a if -2 ** 31 <= a < 2 ** 31 else -1], np.int32))
-            h = self._sync()
+            got, h = self._step_single(a if -2 ** 31 <= a < 2 ** 31 else -1, local=True)
             # the reference's buildLocalObservation indexes a 5x5 frame with ball - fovea_1 + 2 (v5:364-365)
             for b in (h["ball_xy"][0], h["ball1_xy"][0]):
                 for k in (0, 1):
                     idx = int(b[k]) - int(h["fovea_xy"][0][2 + k]) + 2
                     if not -5 <= idx < 5:
                         raise IndexError("index %d is out of bounds for axis with size 5 (lmaze_env_v5.py:364-365)" % idx)
-            return (self._fov(), self._loc(), self._reward_py(h["reward"][0]), self._reward_py(h["foveal_reward"][0]),
+            fov = got["obs"].copy() if "obs" in got else core.obs            # fresh arrays, v5:308,359
+            loc = got["loc"].copy() if "loc" in got else core.obs_local
+            return (fov, loc, self._reward_py(h["reward"][0]), self._reward_py(h["foveal_reward"][0]),
                     bool(h["done"][0]), bool(h["foveal_done"][0]), self.fovealGoal, a)
         core.step(goal)
         self._host = None

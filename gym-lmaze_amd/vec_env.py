@@ -377,9 +377,10 @@ class LmazeVecEnv(object):
         _abi.check("lmaze_render_expanded", rc)
         return out
 
-    def host_state(self):
-        """One device->host copy of every per-env scalar; returns numpy views."""
-        h = self._state.cpu().numpy()
+    def host_state(self, raw=None):
+        """One device->host copy of every per-env scalar; returns numpy views.  raw: bytes of the state block
+        already on the host (uint8 array the size of `_state`), parsed instead of copying again."""
+        h = self._state.cpu().numpy() if raw is None else raw
         base = self._state.data_ptr()
 
         def v(t, dtype, shape):
