@@ -130,6 +130,11 @@ def main():
                              % (args.gpus, args.gpus))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the HIP kernels are the only step path")
+    # LMAZE_BENCH_BACKEND=gloo is a rehearsal switch: several ranks share the visible GPU(s) and the barrier /
+    # MAX go over gloo, to exercise the multi-rank code path on a one-GPU box.  Never used for reported numbers.
+    backend = os.environ.get("LMAZE_BENCH_BACKEND", "nccl")
+    if backend != "nccl":
+        local_rank %= max(1, torch.cuda.device_count())
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     dist = None
@@ -144,7 +149,10 @@ def main():
         saved = os.dup(1)
         os.dup2(2, 1)
         try:
-            dist.init_process_group("nccl", device_id=dev)   # "nccl" is RCCL on ROCm; barrier + one MAX only
+            if backend == "nccl":
+                dist.init_process_group("nccl", device_id=dev)   # "nccl" is RCCL on ROCm; barrier + one MAX only
+            else:
+                dist.init_process_group(backend)
             dist.barrier()
         finally:
             sys.stdout.flush()
@@ -240,7 +248,10 @@ def main():
             try:
                 tj = json.load(open(tpath))
                 key = "g%d_%s" % (G, "perenv" if args.per_env_layouts else "shared")
-                traffic = tj.get(key, {}).get("hbm_bytes_per_launch")
+                rec = tj.get(key, {})
+                # the PMC passes profiled one launch shape: only quote them for that shape
+                if rec.get("algorithmic_bytes_per_launch") == N * B:
+                    traffic = rec.get("hbm_bytes_per_launch")
             except Exception:
                 traffic = None
         out = {
@@ -253,6 +264,8 @@ def main():
                        "parallelism": "independent env shards, no collective on the step path",
                        "actions": "uniform{0..3} int32[%d,N] ring, torch Philox seed 1+rank" % R,
                        "auto_reset": bool(args.auto_reset), "hip_graph": bool(args.graph),
+                       "collective_backend": ("rccl" if backend == "nccl" else backend + " (REHEARSAL, ranks share a GPU)")
+                       if dist is not None else None,
                        "launch_hint": int(env.params.launch_hint),
                        "autotune_ms": {str(k): round(v, 5) for k, v in (tuned or {}).items()}},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
