@@ -107,11 +107,12 @@ hipError_t launch_reset(int variant, const ResetArgs& a, int layout_mode, hipStr
 
 // ------------------------------------------------------------------------------------
 // Reference-layout render: out[i, c, x*E+xx, y*E+yy] = float((obs[i,x,y] & mask[c]) != 0)
-// One workgroup per env; the env's G*G ints and two row/column maps sit in LDS; lanes
-// stripe the env's contiguous C*S*S floats with 16-byte stores.
+// (lmaze_env.py:217-234, lmaze_env_v3.py:295-301).  Pure write stream: 4*C*(G*E)^2 bytes per env.
 // ------------------------------------------------------------------------------------
 
-__global__ __launch_bounds__(LMAZE_BLOCK) void render_expanded_kernel(const ExpandArgs a) {
+// Any shape: one workgroup per env, the env's cells and two row/column maps in LDS, lanes stripe the
+// env's contiguous C*S*S floats with 16-byte stores, index arithmetic by division.
+__global__ __launch_bounds__(LMAZE_BLOCK) void render_expanded_generic_kernel(const ExpandArgs a) {
     extern __shared__ int4 lds4[];
     const int G = a.grid, E = a.expansion, C = a.channels;
     const int CELLS = G * G, S = G * E, PLANE = S * S, L = C * PLANE;
@@ -131,33 +132,95 @@ __global__ __launch_bounds__(LMAZE_BLOCK) void render_expanded_kernel(const Expa
         __syncthreads();
         const size_t B = (size_t)i * L;
         const size_t a0 = (B + 3) & ~(size_t)3, a1 = (B + L) & ~(size_t)3;
-        auto value = [&](int local) -> float {
-            const int c = local / PLANE;
-            const int rem = local - c * PLANE;
-            const int row = rem / S, col = rem - row * S;
-            return (cells[rowmap[row] + colmap[col]] & maskl[c]) ? 1.0f : 0.0f;
-        };
-        // ragged head/tail (only when C*S*S is not a multiple of 4)
-        if (tid < (int)(a0 - B)) a.out[B + tid] = value(tid);
-        if (tid < (int)(B + L - a1)) a.out[a1 + tid] = value((int)(a1 - B) + tid);
-        const int nq = (int)((a1 - a0) >> 2);
+        const int head = (int)(a0 - B), nq = (int)((a1 - a0) >> 2);
         float4* out4 = reinterpret_cast<float4*>(a.out + a0);
-        const int head = (int)(a0 - B);
-        for (int q = tid; q < nq; q += LMAZE_BLOCK) {
-            const int local = head + (q << 2);
-            int c = local / PLANE;
-            int rem = local - c * PLANE;
+        for (int q = tid - 1; q <= nq; q += LMAZE_BLOCK) {           // q = -1 / nq: the ragged head / tail
+            const int first = q < 0 ? 0 : head + (q << 2);
+            const int count = q < 0 ? head : (q == nq ? (int)(B + L - a1) : 4);
+            int c = first / PLANE;
+            const int rem = first - c * PLANE;
             int row = rem / S, col = rem - row * S;
-            float v[4];
+            float v[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                v[j] = (cells[rowmap[row] + colmap[col]] & maskl[c]) ? 1.0f : 0.0f;
+                if (j < count) v[j] = (cells[rowmap[row] + colmap[col]] & maskl[c]) ? 1.0f : 0.0f;
                 if (++col == S) {
                     col = 0;
                     if (++row == S) { row = 0; ++c; }
                 }
             }
-            out4[q] = make_float4(v[0], v[1], v[2], v[3]);
+            if (count == 4) out4[q] = make_float4(v[0], v[1], v[2], v[3]);
+            else
+                for (int j = 0; j < count; ++j) a.out[B + first + j] = v[j];
+        }
+    }
+}
+
+// The reference's shapes (G, E at compile time: the flat index decodes by multiplication).  The output of
+// the whole batch is ONE contiguous stream of N*C*S*S floats; workgroup w writes the aligned stretch
+// [w*CH, (w+1)*CH) of it, whatever envs that covers (at most two, CH <= one env): an env is 94 864 B at
+// 11x11 x7, so per-env workgroups start on 16-byte boundaries only and every 1-KB wave store straddles
+// cache lines (5.3 TB/s); aligned 32-KB stretches reach 6 TB/s and more.
+// LDS: for each of the two envs, cell bits by (grid row, output column): one read per output float.
+template <int GT, int ET, bool NT>
+__global__ __launch_bounds__(LMAZE_BLOCK) void render_expanded_stream_kernel(const ExpandArgs a) {
+    constexpr int CELLS = GT * GT, S = GT * ET, PLANE = S * S;
+    extern __shared__ int4 lds4[];
+    int* cells = reinterpret_cast<int*>(lds4);                      // [2][CELLS]: the (at most) two envs of the stretch
+    int* maskl = cells + 2 * CELLS;                                 // [LMAZE_MAX_CHANNELS]
+    const int C = a.channels, L = C * PLANE, tid = threadIdx.x;
+    const int64_t total = a.n * (int64_t)L;
+    const int64_t f0 = (int64_t)blockIdx.x * a.chunk_floats;        // first float of this workgroup's stretch
+    const int len = (int)min((int64_t)a.chunk_floats, total - f0);
+    int64_t env0 = (int64_t)((double)f0 / (double)L);               // floor(f0 / L), fixed up below
+    if (env0 * L > f0) --env0;
+    if ((env0 + 1) * L <= f0) ++env0;
+    const int off0 = (int)(f0 - env0 * L);
+    const bool two = off0 + len > L;                                // the stretch runs into env0 + 1
+    if (tid < LMAZE_MAX_CHANNELS) maskl[tid] = tid < C ? a.mask[tid] : 0;
+    for (int k = tid; k < (two ? 2 * CELLS : CELLS); k += LMAZE_BLOCK) cells[k] = a.obs[(size_t)env0 * CELLS + k];
+    __syncthreads();
+    float* dst = a.out + f0;
+    static_assert(ET >= 4, "four consecutive output columns span at most two cells");
+    for (int q = tid; (q << 2) < len; q += LMAZE_BLOCK) {
+        int local = off0 + (q << 2);
+        const int* cl = cells;
+        if (local >= L) { local -= L; cl += CELLS; }
+        const int c = local / PLANE;
+        const int rem = local - c * PLANE;
+        const int row = rem / S, col = rem - row * S;
+        // One path for every lane (with S = 77 every wave holds float4s that straddle an output row, so a
+        // branch would cost both sides): the cell under the first column, the next cell of the same grid
+        // row, and the first cell of the following output row -- which may belong to the next plane / env.
+        const int* r0 = cl + (row / ET) * GT;
+        const int k0 = col / ET;
+        const int m0 = maskl[c];
+        const int b0 = r0[k0] & m0, b1 = r0[k0 + 1] & m0;             // r0[GT] is read but never selected
+        int row1 = row + 1, c1 = c;
+        const int* cl1 = cl;
+        if (row1 == S) {
+            row1 = 0;
+            if (++c1 == C) { c1 = 0; cl1 = cells + CELLS; }              // ragged C*S*S only
+        }
+        const int bw = cl1[(row1 / ET) * GT] & maskl[c1];
+        const int edge = (k0 + 1) * ET;                                // first column of the next cell
+        float v[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int cj = col + j;
+            v[j] = (cj >= S ? bw : (cj >= edge ? b1 : b0)) ? 1.0f : 0.0f;
+        }
+        const int count = len - (q << 2);
+        if (count >= 4) {
+            if (NT) {
+                typedef float f4 __attribute__((ext_vector_type(4)));
+                f4 t = {v[0], v[1], v[2], v[3]};
+                __builtin_nontemporal_store(t, reinterpret_cast<f4*>(dst) + q);
+            } else {
+                reinterpret_cast<float4*>(dst)[q] = make_float4(v[0], v[1], v[2], v[3]);
+            }
+        } else {
+            for (int j = 0; j < count; ++j) dst[(q << 2) + j] = v[j];
         }
     }
 }
@@ -231,13 +294,61 @@ hipError_t launch_probe(const void* src, void* dst, int64_t bytes, hipStream_t s
     return hipGetLastError();
 }
 
+static hipError_t launch_expand_generic(const ExpandArgs& a, hipStream_t s) {
+    const int S = a.grid * a.expansion;
+    const unsigned blocks = (unsigned)(a.n < 65536 ? a.n : 65536);
+    const size_t lds = (((size_t)a.grid * a.grid * 4 + LMAZE_MAX_CHANNELS * 4 + (size_t)S * 4) + 15) & ~(size_t)15;
+    hipLaunchKernelGGL(render_expanded_generic_kernel, dim3(blocks), dim3(LMAZE_BLOCK), lds, s, a);
+    return hipGetLastError();
+}
+
+// LDS bytes that make exactly `k` workgroups fit a CU's 160 KiB (as for the step kernel, lmaze_step.hip)
+static size_t expand_lds_for_workgroups_per_cu(int k) {
+    const size_t cap = 160 * 1024;
+    return ((cap / k + cap / (k + 1)) / 2) & ~(size_t)255;
+}
+
+// Launch policy, measured on MI355X (65 536 envs, 6.2 GB of output; TB/s):
+//   stretch x workgroups per CU      32 KiB x 8   32 KiB x 3 + NT   48 KiB x 3 + NT   64 KiB x 3
+//   11x11 x7                            5.7            6.2               5.4              6.4 / erratic
+//   12x12 x7                            5.4            6.2               5.6              6.3 / erratic
+//   18x18 x4                            6.2            6.2               6.0              4.6
+//   32x32 x7                            5.3            5.7               6.2              3.8
+// The same narrow optimum as the step kernel: ~96 KiB of non-temporal stores in flight per CU.
+template <int GT, int ET>
+static hipError_t launch_expand_stream(const ExpandArgs& a, hipStream_t s) {
+    constexpr int S = GT * ET;
+    const int64_t L = (int64_t)a.channels * S * S, total = a.n * L;
+    ExpandArgs b = a;
+    b.chunk_floats = GT >= 32 ? 12288 : 8192;                        // 48 / 32 KiB per workgroup
+    if (b.chunk_floats > L) b.chunk_floats = (int32_t)(L & ~(int64_t)1023);   // a stretch covers two envs at most
+    if (b.chunk_floats < 1024) return launch_expand_generic(a, s);
+    const int64_t chunks = (total + b.chunk_floats - 1) / b.chunk_floats;
+    // out must start on a cache line for the stretches to be aligned
+    if (chunks > 0x7fffffff || ((uintptr_t)a.out & 63)) return launch_expand_generic(a, s);
+    size_t lds = ((size_t)2 * GT * GT * 4 + LMAZE_MAX_CHANNELS * 4 + 15) & ~(size_t)15;
+    const bool nt = total * 4 > ((int64_t)192 << 20);                // cannot stay in the 256 MiB Infinity Cache
+    if (nt) {
+        const size_t want = expand_lds_for_workgroups_per_cu(3);
+        if (want > lds) lds = want;
+        hipLaunchKernelGGL((render_expanded_stream_kernel<GT, ET, true>), dim3((unsigned)chunks), dim3(LMAZE_BLOCK), lds, s, b);
+    } else {
+        hipLaunchKernelGGL((render_expanded_stream_kernel<GT, ET, false>), dim3((unsigned)chunks), dim3(LMAZE_BLOCK), lds, s, b);
+    }
+    return hipGetLastError();
+}
+
 hipError_t launch_expand(const ExpandArgs& a, hipStream_t s) {
     if (a.n == 0) return hipSuccess;
-    const int S = a.grid * a.expansion;
-    const size_t lds = (((size_t)a.grid * a.grid * 4 + LMAZE_MAX_CHANNELS * 4 + (size_t)S * 4) + 15) & ~(size_t)15;
-    const unsigned blocks = (unsigned)(a.n < 65536 ? a.n : 65536);
-    hipLaunchKernelGGL(render_expanded_kernel, dim3(blocks), dim3(LMAZE_BLOCK), lds, s, a);
-    return hipGetLastError();
+    // the reference's own shapes (v0 12x12 x7, v3 18x18 x4) and BASELINE's grids at x7
+    if (a.expansion == 7) {
+        if (a.grid == 12) return launch_expand_stream<12, 7>(a, s);
+        if (a.grid == 11) return launch_expand_stream<11, 7>(a, s);
+        if (a.grid == 8) return launch_expand_stream<8, 7>(a, s);
+        if (a.grid == 32) return launch_expand_stream<32, 7>(a, s);
+    }
+    if (a.expansion == 4 && a.grid == 18) return launch_expand_stream<18, 4>(a, s);
+    return launch_expand_generic(a, s);
 }
 
 }  // namespace lmaze

@@ -63,6 +63,7 @@ struct ExpandArgs {
     int64_t n;
     int32_t grid, expansion, channels;
     int32_t mask[LMAZE_MAX_CHANNELS];
+    int32_t chunk_floats;  // stream kernel: floats per workgroup (multiple of 1024, <= one env)
 };
 
 // device-resident epoch words of the *_autoreset entry points: 8-byte aligned, epoch_out only together with

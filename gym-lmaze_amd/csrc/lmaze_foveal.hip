@@ -683,6 +683,61 @@ __global__ __launch_bounds__(LMAZE_BLOCK) void expand_planes_kernel(const Expand
     }
 }
 
+// The foveal shape itself (5x5 window, x7; every foveal variant): g and E at compile time, so the flat index
+// decodes by multiplication, and the output treated as what it is -- ONE contiguous stream of N*C planes of
+// 35x35 floats.  Workgroup w writes the aligned stretch [w*CH, (w+1)*CH) floats of it (an env is 19.6-34 KB
+// and starts on a 16-byte boundary only: per-env workgroups straddle cache lines with every wave store).
+template <int GT, int ET, bool NT>
+__global__ __launch_bounds__(LMAZE_BLOCK) void expand_planes_stream_kernel(const ExpandPlanesArgs a, int chunk_floats) {
+    constexpr int PC = GT * GT, S = GT * ET, PLANE = S * S;
+    extern __shared__ int4 lds4[];
+    float* src = reinterpret_cast<float*>(lds4);                    // [planes touched][PC]
+    const int tid = threadIdx.x;
+    const int64_t total = a.n * (int64_t)a.channels * PLANE;
+    const int64_t f0 = (int64_t)blockIdx.x * chunk_floats;
+    const int len = (int)min((int64_t)chunk_floats, total - f0);
+    const int64_t p0 = f0 / PLANE;                                  // first plane of the stretch (plane = env*C + c)
+    const int off0 = (int)(f0 - p0 * PLANE);
+    const int np = (off0 + len + PLANE - 1) / PLANE;
+    for (int k = tid; k < np * PC; k += LMAZE_BLOCK) src[k] = a.planes[(size_t)p0 * PC + k];
+    __syncthreads();
+    float* dst = a.out + f0;
+    static_assert(ET >= 4, "four consecutive output columns span at most two cells");
+    for (int q = tid; (q << 2) < len; q += LMAZE_BLOCK) {
+        const int local = off0 + (q << 2);
+        const int p = local / PLANE;
+        const int rem = local - p * PLANE;
+        const int row = rem / S, col = rem - row * S;
+        // one path for every lane (S = 35: every wave holds float4s that straddle an output row): the value
+        // under the first column, the next one of the same window row, and the first of the following row
+        const float* r0 = src + p * PC + (row / ET) * GT;
+        const int k0 = col / ET;
+        const float v0 = r0[k0], v1 = r0[k0 + 1];                      // r0[GT] is read but never selected
+        int row1 = row + 1, p1 = p;
+        if (row1 == S) { row1 = 0; ++p1; }
+        const float vw = src[p1 * PC + (row1 / ET) * GT];
+        const int edge = (k0 + 1) * ET;
+        float v[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int cj = col + j;
+            v[j] = cj >= S ? vw : (cj >= edge ? v1 : v0);
+        }
+        const int count = len - (q << 2);
+        if (count >= 4) {
+            if (NT) {
+                typedef float f4 __attribute__((ext_vector_type(4)));
+                f4 t = {v[0], v[1], v[2], v[3]};
+                __builtin_nontemporal_store(t, reinterpret_cast<f4*>(dst) + q);
+            } else {
+                reinterpret_cast<float4*>(dst)[q] = make_float4(v[0], v[1], v[2], v[3]);
+            }
+        } else {
+            for (int j = 0; j < count; ++j) dst[(q << 2) + j] = v[j];
+        }
+    }
+}
+
 // ------------------------------------------------------------------------------------
 // host side
 // ------------------------------------------------------------------------------------
@@ -876,6 +931,25 @@ int lmaze_expand_planes(const float* planes, int32_t channels, int32_t g, int32_
     a.channels = channels;
     a.g = g;
     a.expansion = expansion;
+    if (g == FOV && expansion == 7 && !((uintptr_t)out & 63)) {
+        // measured (262 144 envs, C = 4/5/7): 32 KiB x 8 per CU 5.2 TB/s; 48 KiB x 2 per CU + non-temporal 6.2-6.4
+        const int chunk = 12288;
+        const int64_t total = n * (int64_t)channels * (FOV * 7) * (FOV * 7);
+        const int64_t chunks = (total + chunk - 1) / chunk;
+        if (chunks <= 0x7fffffff) {
+            size_t lds = ((size_t)(chunk / ((FOV * 7) * (FOV * 7)) + 3) * W25 * 4 + 15) & ~(size_t)15;   // planes touched + one of slack
+            if (total * 4 > ((int64_t)192 << 20)) {
+                const size_t cap = 160 * 1024, want = ((cap / 2 + cap / 3) / 2) & ~(size_t)255;      // 2 workgroups per CU
+                if (want > lds) lds = want;
+                hipLaunchKernelGGL((expand_planes_stream_kernel<FOV, 7, true>), dim3((unsigned)chunks), dim3(LMAZE_BLOCK), lds,
+                                   (hipStream_t)stream, a, chunk);
+            } else {
+                hipLaunchKernelGGL((expand_planes_stream_kernel<FOV, 7, false>), dim3((unsigned)chunks), dim3(LMAZE_BLOCK), lds,
+                                   (hipStream_t)stream, a, chunk);
+            }
+            return (int)hipGetLastError();
+        }
+    }
     const int S = g * expansion;
     const size_t lds = (((size_t)channels * g * g * 4 + (size_t)S * 4) + 15) & ~(size_t)15;
     const unsigned blocks = (unsigned)(n < 65536 ? n : 65536);

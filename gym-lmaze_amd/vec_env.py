@@ -235,12 +235,15 @@ class LmazeVecEnv(object):
                                    self._p_reward, self._p_done, self._p_gc, obs_ptr, N, st)
         _abi.check("lmaze_step_" + self.variant, rc)
 
-    def autotune(self, auto_reset=False, steps=4, candidates=(8, 4, 3, 2)):
+    def autotune(self, auto_reset=False, steps=8, candidates=(8, 4, 3, 2), warm=150):
         """Pick the launch policy (LmazeParams.launch_hint = workgroups per CU) by timing real
         steps with HIP events; the state is snapshotted and restored, so results are unaffected.
         The best cap is narrow and shifts with (G, N, auto_reset) and between devices (see
-        lmaze_step.hip launch_shared), which is why it is measured rather than fixed.  Returns
-        {candidate: ms per step}.  Only the shared-layout kernel has this knob."""
+        lmaze_step.hip launch_shared), which is why it is measured rather than fixed.  `warm` untimed
+        launches come first: a cold device (the first ~100 launches of a process) ranks the candidates
+        differently from the steady state -- 4 per CU looks best cold and is 20 % behind 3 per CU once
+        warm (tools/autotune_study.py) -- and the steady state is what a rollout runs in.
+        Returns {candidate: ms per step}.  Only the shared-layout kernel has this knob."""
         obs_bytes = self.num_envs * self.grid * self.grid * 4
         if self.layout_mode != _abi.LAYOUT_SHARED or obs_bytes <= (192 << 20):
             return {}       # the cap only pays in the streaming (non-temporal store) regime
@@ -248,9 +251,11 @@ class LmazeVecEnv(object):
         a = torch.randint(0, 4, (self.num_envs,), dtype=torch.int32, device=self.device)
         timings = {}
         with self._guard():
+            for _ in range(int(warm)):
+                self._launch_step(a.data_ptr(), self._p_obs, auto_reset)
             for c in candidates:
                 self.params.launch_hint = int(c)
-                self._launch_step(a.data_ptr(), self._p_obs, auto_reset)      # warm
+                self._launch_step(a.data_ptr(), self._p_obs, auto_reset)      # first launch of a new shape
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 e0.record()
                 for _ in range(steps):
@@ -258,8 +263,8 @@ class LmazeVecEnv(object):
                 e1.record()
                 e1.synchronize()
                 timings[int(c)] = e0.elapsed_time(e1) / steps
-                self._state.copy_(snap)
-                self._epoch = epoch
+            self._state.copy_(snap)
+            self._epoch = epoch
         self.params.launch_hint = min(timings, key=timings.get)
         self.observe()
         return timings

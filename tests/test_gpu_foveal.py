@@ -172,7 +172,7 @@ def test_reset_placement_rules(variant):
     assert (h["step_count"] == 0).all() and (f32_bits(h["reward"]) == f32_bits(np.float32(-0.0))).all()
 
 
-@pytest.mark.parametrize("C,g,E", [(4, 5, 7), (5, 5, 7), (7, 5, 7), (3, 4, 3), (1, 5, 1), (16, 5, 2)])
+@pytest.mark.parametrize("C,g,E", [(4, 5, 7), (5, 5, 7), (7, 5, 7), (1, 5, 7), (3, 5, 7), (16, 5, 7), (3, 4, 3), (1, 5, 1), (16, 5, 2)])
 def test_expand_planes_matches_oracle(C, g, E):
     abi = importlib.import_module("gym-lmaze_amd._abi")
     N = 19

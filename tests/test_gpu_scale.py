@@ -271,3 +271,35 @@ def test_foveal_captured_autoreset_steps(variant):
         for k in he:
             assert (he[k].view(np.uint8) == hg[k].view(np.uint8)).all(), (k, rep)
         assert (eager.obs.view(torch.int32) == graphed.obs.view(torch.int32)).all(), rep
+
+
+@pytest.mark.parametrize("G,E,cmask", [(11, 7, (1, 2, 4, 8)), (12, 7, (1, 2, 4, 8)), (18, 4, (8, 1, 4)), (32, 7, (1, 2, 4, 8))])
+def test_render_expanded_streaming_regime(G, E, cmask):
+    """Outputs beyond 192 MiB take the non-temporal, occupancy-capped launch: same floats as the definition
+    out[i,c,x*E+xx,y*E+yy] = (obs[i,x,y] & mask[c]) != 0, written here with torch ops."""
+    import ctypes as C
+    abi = importlib.import_module("gym-lmaze_amd._abi")
+    per_env = len(cmask) * (G * E) ** 2 * 4
+    N = (200 << 20) // per_env + 3                                     # just past the threshold, ragged count
+    obs = torch.randint(0, 16, (N, G, G), dtype=torch.int32, device="cuda")
+    out = torch.full((N, len(cmask), G * E, G * E), -1.0, dtype=torch.float32, device="cuda")
+    m = (C.c_int32 * len(cmask))(*cmask)
+    assert abi.lib.lmaze_render_expanded(obs.data_ptr(), G, E, m, len(cmask), out.data_ptr(), N,
+                                         torch.cuda.current_stream().cuda_stream) == 0
+    masks = torch.tensor(cmask, dtype=torch.int32, device="cuda")[None, :, None, None]
+    for lo in range(0, N, 256):                                        # in slices: the torch expression is memory-hungry
+        want = ((obs[lo:lo + 256, None] & masks) != 0).to(torch.float32)
+        want = want.repeat_interleave(E, dim=2).repeat_interleave(E, dim=3)
+        assert torch.equal(out[lo:lo + 256], want), lo
+
+
+@pytest.mark.parametrize("Cn", [4, 5, 7])
+def test_expand_planes_streaming_regime(Cn):
+    abi = importlib.import_module("gym-lmaze_amd._abi")
+    N = (200 << 20) // (Cn * 35 * 35 * 4) + 5
+    planes = torch.rand((N, Cn, 5, 5), dtype=torch.float32, device="cuda")
+    out = torch.full((N, Cn, 35, 35), -1.0, dtype=torch.float32, device="cuda")
+    assert abi.lib.lmaze_expand_planes(planes.data_ptr(), Cn, 5, 7, out.data_ptr(), N,
+                                       torch.cuda.current_stream().cuda_stream) == 0
+    want = planes.repeat_interleave(7, dim=2).repeat_interleave(7, dim=3)
+    assert torch.equal(out.view(torch.int32), want.view(torch.int32))
