@@ -771,8 +771,10 @@ template <int MODE>
 static hipError_t launch_foveal_mode(const FovealArgs& a, hipStream_t s) {
     if (a.n == 0) return hipSuccess;
     switch (a.p.variant) {
-        case LMAZE_VARIANT_V1: return launch_foveal_one<LMAZE_VARIANT_V1, MODE, 256>(a, s);
-        case LMAZE_VARIANT_V2: return launch_foveal_one<LMAZE_VARIANT_V2, MODE, 256>(a, s);
+        // envs per workgroup, measured warm at 1M envs (TB/s of algorithmic traffic, 256 / 128 / 64 envs):
+        //   v1 (400 B of observation per env)  5.9-6.0 / 6.1 / 6.7-6.8      v2 (500 B)  5.9 / 6.1 / 5.8
+        case LMAZE_VARIANT_V1: return launch_foveal_one<LMAZE_VARIANT_V1, MODE, 64>(a, s);
+        case LMAZE_VARIANT_V2: return launch_foveal_one<LMAZE_VARIANT_V2, MODE, 128>(a, s);
         case LMAZE_VARIANT_V5:
         case LMAZE_VARIANT_V6:
             return launch_foveal_one<LMAZE_VARIANT_V5, MODE, 64>(a, s);
@@ -884,7 +886,7 @@ int lmaze_v1_set_foveal_goal(const LmazeFovealParams* params, const uint8_t* lay
     a.action = ij;
     a.mask = mask;
     if (n == 0) return 0;
-    return (int)launch_foveal_one<LMAZE_VARIANT_V1, FM_SETGOAL, 256>(a, (hipStream_t)stream);
+    return (int)launch_foveal_one<LMAZE_VARIANT_V1, FM_SETGOAL, 64>(a, (hipStream_t)stream);
 }
 
 int lmaze_v5_planner_step(const LmazeFovealParams* params, const uint8_t* layouts, const int32_t* goal,

@@ -24,6 +24,14 @@ def main():
     import torch
     pkg = importlib.import_module("gym-lmaze_amd")
     N = args.envs
+    # warm the device first: the first ~100 launches of a process run 10-40 % slow (clocks still ramping) and
+    # would be charged to whichever variant is measured first
+    w = pkg.LmazeVecEnv(N, variant="v0", layout=pkg.layouts.to_codes(pkg.layouts.open_room(11, (5, 5))))
+    a0 = torch.randint(0, 4, (N,), dtype=torch.int32, device="cuda")
+    for _ in range(400):
+        w.step_raw(a0.data_ptr())
+    torch.cuda.synchronize()
+    del w, a0
     for variant in ("v1", "v2", "v4", "v5"):
         env = pkg.LmazeFovealVecEnv(N, variant=variant, seed=1)
         hi = 4 if variant in ("v1", "v5") else 25
