@@ -7,6 +7,12 @@ if the library is missing or does not load, importing this module raises.  Build
 import ctypes as C
 import os
 
+# torch FIRST: its wheel bundles its own libamdhip64 / libhsa-runtime64, and liblmaze_hip.so needs the same
+# sonames.  Loaded in this order the dynamic linker gives both ONE HIP runtime (torch's); loaded the other
+# way round the process ends up with two HSA runtimes and the second one finds no device (every launch then
+# fails with hipErrorNoDevice) -- seen on MI355X with `import gym_lmaze` before `import torch`.
+import torch  # noqa: F401
+
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "liblmaze_hip.so")
 
