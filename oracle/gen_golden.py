@@ -112,8 +112,9 @@ def layout_random(G, seed, p_wall=0.25):
 # ----------------------------------------------------------------------------------------
 # v0  (lmaze_env.py)
 # ----------------------------------------------------------------------------------------
-def rollout_v0(grid, actions, seed, reset_on_done=True):
+def rollout_v0(grid, actions, seed, reset_on_done=True, random_ball=True):
     env = ref_loader.make("v0")
+    env.RANDOM_BALL = random_ball            # flipped after construction, as a user does (lmaze_env.py:25,70,82-89)
     if grid is not None:  # re-size the reference by attribute override
         env.grid = grid
         env.realgrid = grid.shape[0]
@@ -121,7 +122,7 @@ def rollout_v0(grid, actions, seed, reset_on_done=True):
     E, G = env.expansionRatio, env.realgrid
     random.seed(seed)
     T = len(actions)
-    rec = dict(layout=to_codes(env.grid), E=np.int32(E), seed=np.int64(seed),
+    rec = dict(layout=to_codes(env.grid), E=np.int32(E), seed=np.int64(seed), random_ball=np.uint8(random_ball),
                actions=np.asarray(actions, dtype=np.int32),
                reset_before=np.zeros(T, np.uint8), ball_before=np.zeros((T, 2), np.int32),
                reward=np.zeros(T, np.float64), done=np.zeros(T, np.uint8),
@@ -160,8 +161,10 @@ def rollout_v0(grid, actions, seed, reset_on_done=True):
 # ----------------------------------------------------------------------------------------
 # v3  (lmaze_env_v3.py): string actions, random goal, look-ahead goal test
 # ----------------------------------------------------------------------------------------
-def rollout_v3(actions, seed, mode="train", grid=None, reset_on_done=True):
+def rollout_v3(actions, seed, mode="train", grid=None, reset_on_done=True, random_ball=True, random_goal=True):
+    random.seed(seed)                        # the constructor's own reset() draws too (lmaze_env_v3.py:125)
     env = ref_loader.make("v3")
+    env.RANDOM_BALL, env.RANDOM_GOAL = random_ball, random_goal      # lmaze_env_v3.py:100-101,147-164
     if grid is not None:
         env.grid = grid
         env.realgrid = grid.shape[0]
@@ -172,6 +175,7 @@ def rollout_v3(actions, seed, mode="train", grid=None, reset_on_done=True):
     random.seed(seed)
     T = len(actions)
     rec = dict(layout=to_codes(env.grid), E=np.int32(E), seed=np.int64(seed),
+               random_ball=np.uint8(random_ball), random_goal=np.uint8(random_goal),
                mode_test=np.uint8(mode == "test"),
                actions=np.asarray(actions, dtype=np.int32),
                reset_before=np.zeros(T, np.uint8), ball_before=np.zeros((T, 2), np.int32),
@@ -293,7 +297,7 @@ def foveal_actions(seed, T):
     return np.random.RandomState(seed).randint(0, 25, T).astype(np.int32)
 
 
-def rollout_v24(variant, actions, seed, reset_on_done=True):
+def rollout_v24(variant, actions, seed, reset_on_done=True, random_ball=True, random_goal=True):
     """v2 (lmaze_env_v2.py) and v4 (lmaze_env_v4.py): 25-way teleport-in-fovea action."""
     five_layouts()
     import contextlib
@@ -301,9 +305,11 @@ def rollout_v24(variant, actions, seed, reset_on_done=True):
     random.seed(seed)
     np.random.seed(seed)
     env = ref_loader.make(variant)          # the constructor already ran one reset()
+    env.RANDOM_BALL, env.RANDOM_GOAL = random_ball, random_goal      # lmaze_env_v2.py:51-52,277-299
     E, C = env.expansionRatio, env.stateChannel
     T = len(actions)
     rec = dict(E=np.int32(E), seed=np.int64(seed), layouts=five_layouts(),
+               random_ball=np.uint8(random_ball), random_goal=np.uint8(random_goal),
                actions=np.asarray(actions, dtype=np.int32),
                reset_before=np.zeros(T, np.uint8), ball_before=np.zeros((T, 2), np.int32),
                goal_before=np.zeros((T, 2), np.int32), layout_id=np.zeros(T, np.int32),
@@ -546,54 +552,17 @@ def gen_v6():
 
 
 # ----------------------------------------------------------------------------------------
-# the placement switches the reference exposes as plain attributes (RANDOM_BALL / RANDOM_GOAL)
+# the placement switches the reference exposes as plain attributes (RANDOM_BALL / RANDOM_GOAL), flipped
+# after construction: start cell 'S' (lmaze_env.py:82-89), goal kept from the constructor's reset
+# (lmaze_env_v3.py:147) or looked up at 'X' (lmaze_env_v2.py:284-286)
 # ----------------------------------------------------------------------------------------
-def rollout_flags(variant, actions, seed, random_ball, random_goal=None):
-    """v0 / v3 / v2 with the switches flipped after construction: start cell 'S' (lmaze_env.py:82-89),
-    goal at the 'X' cell (lmaze_env_v3.py:116-117 keeps it; lmaze_env_v2.py:284-286 looks it up)."""
-    random.seed(seed)
-    np.random.seed(seed)
-    env = ref_loader.make(variant)
-    env.RANDOM_BALL = random_ball
-    if random_goal is not None:
-        env.RANDOM_GOAL = random_goal
-    E = env.expansionRatio
-    T = len(actions)
-    rec = dict(E=np.int32(E), seed=np.int64(seed), random_ball=np.uint8(random_ball),
-               random_goal=np.uint8(1 if random_goal is None else random_goal),
-               actions=np.asarray(actions, dtype=np.int32), reset_before=np.zeros(T, np.uint8),
-               ball_before=np.zeros((T, 2), np.int32), goal_before=np.zeros((T, 2), np.int32),
-               reward=np.zeros(T, np.float64), done=np.zeros(T, np.uint8), ball=np.zeros((T, 2), np.int32),
-               obs_hash=np.zeros(T, np.uint64))
-    reset_hash = []
-    need_reset = True
-    for t in range(T):
-        if need_reset:
-            o = env.reset()
-            reset_hash.append(obs_hash(np.ascontiguousarray(o)))
-            rec["reset_before"][t] = 1
-            need_reset = False
-        rec["ball_before"][t] = (env.ball_x0, env.ball_y0)
-        rec["goal_before"][t] = (env.goal_x, env.goal_y)
-        a = int(actions[t])
-        arg = (str(a) if 0 <= a <= 3 else a) if variant == "v3" else a
-        o, r, d, _ = env.step(arg)
-        rec["reward"][t] = r
-        rec["done"][t] = d
-        rec["ball"][t] = (env.ball_x0, env.ball_y0)
-        rec["obs_hash"][t] = obs_hash(np.ascontiguousarray(o))
-        need_reset = bool(d)
-    rec["reset_hash"] = np.array(reset_hash, np.uint64)
-    return rec
-
-
 def gen_flags():
     a4 = np.random.RandomState(71).randint(0, 4, 260).astype(np.int32)
-    save("flags_v0_fixed_start", rollout_flags("v0", a4, 0, random_ball=False))
-    save("flags_v3_fixed_start_goal", rollout_flags("v3", a4, 1, random_ball=False, random_goal=False))
-    save("flags_v3_fixed_goal", rollout_flags("v3", a4, 2, random_ball=True, random_goal=False))
-    save("flags_v2_fixed_goal", rollout_flags("v2", foveal_actions(72, 160), 3, random_ball=True, random_goal=False))
-    save("flags_v2_fixed_start", rollout_flags("v2", foveal_actions(73, 160), 4, random_ball=False, random_goal=True))
+    save("v0_fixed_start_seed0", rollout_v0(None, a4, seed=0, random_ball=False))
+    save("v3_fixed_start_goal_seed1", rollout_v3(a4, seed=1, random_ball=False, random_goal=False))
+    save("v3_fixed_goal_seed2", rollout_v3(a4, seed=2, random_goal=False))
+    save("v2_fixed_goal_seed3", rollout_v24("v2", foveal_actions(72, 160), seed=3, random_goal=False))
+    save("v2_fixed_start_seed4", rollout_v24("v2", foveal_actions(73, 160), seed=4, random_ball=False))
 
 
 GENERATORS = {"v0": gen_v0, "v3": gen_v3, "v1": gen_v1, "v2": gen_v2, "v4": gen_v4, "v5": gen_v5, "v6": gen_v6,
