@@ -523,3 +523,31 @@ def test_package_imported_before_torch_still_finds_the_device():
             "print('OK', o.shape, r, d, a)\n" % root)
     out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300)
     assert out.returncode == 0 and "OK (4, 84, 84)" in out.stdout, out.stderr[-2000:]
+
+
+def test_random_shapes_fuzz():
+    """Forty seeded random (variant, G, N, layout mode) combinations through the same step-by-step
+    comparison, to reach grid sizes and batch sizes the parametrised cases above do not name."""
+    rs = np.random.RandomState(20261004)
+    for case in range(40):
+        variant = "v3" if rs.rand() < 0.5 else "v0"
+        shared = rs.rand() < 0.5
+        G = int(rs.randint(4, 65)) if shared else int(rs.randint(4, 41))
+        N = int(rs.choice([1, 2, 7, 64, 65, 130, 257, 1000, 2049]))
+        if not shared:
+            N = min(N, 600)
+        T = 12 if G <= 24 else 5
+        try:
+            _compare_rollout(variant, N, G, T, shared=shared, seed=1000 + case, action_hi=9)
+        except AssertionError as e:
+            raise AssertionError("case %d: %s G=%d N=%d shared=%s: %s" % (case, variant, G, N, shared, e))
+
+
+def test_fused_autoreset_fuzz():
+    """Ten more seeded (variant, layout mode, G) combinations of the fused auto-reset comparison."""
+    rs = np.random.RandomState(77)
+    for case in range(10):
+        variant = "v3" if rs.rand() < 0.5 else "v0"
+        shared = bool(rs.rand() < 0.5)
+        G = int(rs.randint(5, 41))
+        test_fused_autoreset_equals_reset_then_step(variant, shared, G)
