@@ -262,6 +262,21 @@ class LmazeFovealVecEnv(object):
         _abi.check("lmaze_expand_planes", rc)
         return out
 
+    def episode_stats(self, all_ranks=False):
+        """Counters over the batch, off the step path (lmaze_episode_stats): {"done", "goal_rewards",
+        "done_steps"} -- envs with done set, envs whose reward is the goal reward, step counts summed over
+        the done envs.  all_ranks=True sums them over the process group (one small all_reduce).  Synchronises."""
+        out = torch.empty(4, dtype=torch.int64, device=self.device)
+        with self._guard():
+            rc = _abi.lib.lmaze_episode_stats(self._done_u8.data_ptr(), self.reward.data_ptr(), self.step_count.data_ptr(),
+                                              None, self.params.reward_goal, self.num_envs, out.data_ptr(), self._stream())
+        _abi.check("lmaze_episode_stats", rc)
+        if all_ranks:
+            from .sharding import sum_over_ranks
+            out = sum_over_ranks(out, device=self.device)
+        v = out.tolist()
+        return {"done": v[0], "goal_rewards": v[1], "done_steps": v[2]}
+
     def host_state(self, raw=None):
         """Every per-env scalar on the host (numpy views of one copy of the state block; raw = that block
         already fetched by the caller)."""

@@ -424,3 +424,20 @@ def test_foveal_fused_autoreset_equals_reset_then_step(variant):
             assert (_bits(_np(fused.visit)) == _bits(_np(split.visit))).all(), t
         assert (_bits(_np(fused.obs)) == _bits(_np(split.obs))).all(), t
     assert n_resets >= N
+
+
+@pytest.mark.parametrize("variant", ["v2", "v4", "v5"])
+def test_foveal_episode_stats(variant):
+    N = 5000
+    env = PKG.LmazeFovealVecEnv(N, variant=variant, seed=8)
+    rs = np.random.RandomState(8)
+    hi = 4 if variant == "v5" else 25
+    if variant == "v5":
+        env.planner_step(torch.from_numpy(rs.randint(0, 25, N).astype(np.int32)))
+    for t in range(60):
+        env.step(torch.from_numpy(rs.randint(0, hi, N).astype(np.int32)))
+    h = env.host_state()
+    st = env.episode_stats()
+    goal = np.float32(env.params.reward_goal)
+    assert st["done"] == int(h["done"].sum()) and st["goal_rewards"] == int((h["reward"] == goal).sum())
+    assert st["done_steps"] == int(h["step_count"][h["done"] != 0].sum()) and st["done"] > 0
