@@ -225,7 +225,8 @@ int lmaze_render_expanded(const int32_t* obs, int32_t grid, int32_t expansion, c
     a.grid = grid;
     a.expansion = expansion;
     a.channels = channels;
-    a.chunk_floats = 0;   // chosen by the launcher
+    a.chunk_floats = 0;   // chosen by the launcher, like the reciprocals
+    a.inv_l = a.inv_cells = 0;
     for (int c = 0; c < LMAZE_MAX_CHANNELS; ++c) a.mask[c] = c < channels ? channel_mask_host[c] : 0;
     return (int)launch_expand(a, (hipStream_t)stream);
 }

@@ -302,6 +302,78 @@ static hipError_t launch_expand_generic(const ExpandArgs& a, hipStream_t s) {
     return hipGetLastError();
 }
 
+// E = 1: the reference's unexpanded planes float32[N,C,G,G] (what it calls retState, lmaze_env.py:208-215) --
+// the layout a policy network takes.  Any G.  Same aligned-stretch scheme: the workgroup stages the cells of
+// the few envs its stretch covers (contiguous in obs; 16-byte loads when aligned, four dword loads in flight
+// per lane otherwise) and every lane turns four consecutive output floats into one 16-byte store.  (Reading
+// the cells per lane straight from obs instead: 2.0-3.6 TB/s.)  The two divisions of the index decode are
+// multiplications by reciprocals the host computed (exact for the < 2^17 values that occur).
+template <bool NT>
+__global__ __launch_bounds__(LMAZE_BLOCK) void render_planes_stream_kernel(const ExpandArgs a) {
+    extern __shared__ int4 lds4[];
+    int* cells = reinterpret_cast<int*>(lds4);                      // [envs of the stretch][CELLS] (+ slack)
+    const int G = a.grid, C = a.channels, CELLS = G * G, L = C * CELLS, tid = threadIdx.x;
+    const int64_t total = a.n * (int64_t)L;
+    const int64_t f0 = (int64_t)blockIdx.x * a.chunk_floats;
+    const int len = (int)min((int64_t)a.chunk_floats, total - f0);
+    int64_t env0 = (int64_t)((double)f0 / (double)L);               // floor(f0 / L), fixed up below
+    if (env0 * L > f0) --env0;
+    if ((env0 + 1) * L <= f0) ++env0;
+    const int off0 = (int)(f0 - env0 * L);
+    const int ne = (int)min((int64_t)((off0 + len + L - 1) / L), a.n - env0);
+    __shared__ int maskl[LMAZE_MAX_CHANNELS + 1];
+    if (tid <= LMAZE_MAX_CHANNELS) maskl[tid] = tid < C ? a.mask[tid] : 0;
+    {
+        const int32_t* src = a.obs + (size_t)env0 * CELLS;
+        const int nint = ne * CELLS;
+        if ((((uintptr_t)src) & 15) == 0) {                          // 16-byte loads when the first env starts aligned
+            const int n4 = nint >> 2;
+            for (int k = tid; k < n4; k += LMAZE_BLOCK) reinterpret_cast<int4*>(cells)[k] = reinterpret_cast<const int4*>(src)[k];
+            for (int k = (n4 << 2) + tid; k < nint; k += LMAZE_BLOCK) cells[k] = src[k];
+        } else {
+            for (int k = tid; k < nint; k += 4 * LMAZE_BLOCK) {      // four loads in flight per lane
+                int v[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) v[u] = (k + u * LMAZE_BLOCK < nint) ? src[k + u * LMAZE_BLOCK] : 0;
+#pragma unroll
+                for (int u = 0; u < 4; ++u)
+                    if (k + u * LMAZE_BLOCK < nint) cells[k + u * LMAZE_BLOCK] = v[u];
+            }
+        }
+    }
+    __syncthreads();
+    float* dst = a.out + f0;
+    for (int q = tid; (q << 2) < len; q += LMAZE_BLOCK) {
+        const uint32_t local = (uint32_t)(off0 + (q << 2));
+        const uint32_t le = (uint32_t)(((uint64_t)local * a.inv_l) >> 32);           // env of the stretch
+        const uint32_t rem = local - le * (uint32_t)L;
+        const uint32_t c = (uint32_t)(((uint64_t)rem * a.inv_cells) >> 32);          // plane
+        const int cell = (int)(rem - c * (uint32_t)CELLS);
+        const bool last = (int)c + 1 == C;
+        const int* r0 = cells + le * CELLS;
+        const int* r1 = last ? r0 + CELLS : r0;
+        const int m0 = maskl[c], m1 = maskl[last ? 0 : c + 1];
+        float v[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int cj = cell + j;
+            v[j] = (cj < CELLS ? (r0[cj] & m0) : (r1[cj - CELLS] & m1)) ? 1.0f : 0.0f;
+        }
+        const int count = len - (q << 2);
+        if (count >= 4) {
+            if (NT) {
+                typedef float f4 __attribute__((ext_vector_type(4)));
+                f4 t = {v[0], v[1], v[2], v[3]};
+                __builtin_nontemporal_store(t, reinterpret_cast<f4*>(dst) + q);
+            } else {
+                reinterpret_cast<float4*>(dst)[q] = make_float4(v[0], v[1], v[2], v[3]);
+            }
+        } else {
+            for (int j = 0; j < count; ++j) dst[(q << 2) + j] = v[j];
+        }
+    }
+}
+
 // LDS bytes that make exactly `k` workgroups fit a CU's 160 KiB (as for the step kernel, lmaze_step.hip)
 static size_t expand_lds_for_workgroups_per_cu(int k) {
     const size_t cap = 160 * 1024;
@@ -338,8 +410,28 @@ static hipError_t launch_expand_stream(const ExpandArgs& a, hipStream_t s) {
     return hipGetLastError();
 }
 
+static hipError_t launch_planes_stream(const ExpandArgs& a, hipStream_t s) {
+    const int64_t cells = (int64_t)a.grid * a.grid, L = a.channels * cells, total = a.n * L;
+    ExpandArgs b = a;
+    b.chunk_floats = 8192;                                           // 32 KiB per workgroup
+    const int64_t chunks = (total + b.chunk_floats - 1) / b.chunk_floats;
+    if (cells < 4 || chunks > 0x7fffffff || ((uintptr_t)a.out & 63)) return launch_expand_generic(a, s);
+    b.inv_l = (((uint64_t)1 << 32) + (uint64_t)L - 1) / (uint64_t)L;
+    b.inv_cells = (((uint64_t)1 << 32) + (uint64_t)cells - 1) / (uint64_t)cells;
+    size_t lds = ((size_t)(b.chunk_floats / L + 3) * cells * 4 + 15) & ~(size_t)15;
+    // read + write stream (the input is 20 % of the traffic): as for the per-env step kernel, capping the
+    // occupancy only hurts -- 1M x 11x11: 5.9 TB/s uncapped, 5.0 at 4 workgroups per CU, 4.1 at 3
+    if (total * 4 > ((int64_t)192 << 20)) {
+        hipLaunchKernelGGL((render_planes_stream_kernel<true>), dim3((unsigned)chunks), dim3(LMAZE_BLOCK), lds, s, b);
+    } else {
+        hipLaunchKernelGGL((render_planes_stream_kernel<false>), dim3((unsigned)chunks), dim3(LMAZE_BLOCK), lds, s, b);
+    }
+    return hipGetLastError();
+}
+
 hipError_t launch_expand(const ExpandArgs& a, hipStream_t s) {
     if (a.n == 0) return hipSuccess;
+    if (a.expansion == 1) return launch_planes_stream(a, s);
     // the reference's own shapes (v0 12x12 x7, v3 18x18 x4) and BASELINE's grids at x7
     if (a.expansion == 7) {
         if (a.grid == 12) return launch_expand_stream<12, 7>(a, s);

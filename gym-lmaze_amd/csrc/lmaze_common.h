@@ -63,7 +63,8 @@ struct ExpandArgs {
     int64_t n;
     int32_t grid, expansion, channels;
     int32_t mask[LMAZE_MAX_CHANNELS];
-    int32_t chunk_floats;  // stream kernel: floats per workgroup (multiple of 1024, <= one env)
+    int32_t chunk_floats;  // stream kernels: floats per workgroup (multiple of 1024; x E: <= one env)
+    uint64_t inv_l, inv_cells;  // x1 planes kernel: ceil(2^32 / (C*G*G)), ceil(2^32 / (G*G))
 };
 
 // device-resident epoch words of the *_autoreset entry points: 8-byte aligned, epoch_out only together with

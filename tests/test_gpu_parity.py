@@ -384,7 +384,9 @@ def test_fused_autoreset_equals_reset_then_step(variant, shared, G):
 @pytest.mark.parametrize("G,E,cmask", [(12, 7, (1, 2, 4, 8)), (11, 7, (1, 2, 4, 8)), (18, 4, (8, 1, 4)),
                                        (5, 7, (1, 2, 4, 8, 3)), (5, 7, (8, 4, 1)), (9, 3, (1, 2, 4)),
                                        (32, 7, (1, 2, 4, 8)), (8, 1, (1,)), (8, 7, (1, 2, 4, 8)), (7, 7, (4, 1, 256)),
-                                       (63, 5, (1, 2, 4)), (64, 16, (2,)), (3, 16, (1, 8))])
+                                       (63, 5, (1, 2, 4)), (64, 16, (2,)), (3, 16, (1, 8)),
+                                       (11, 1, (1, 2, 4, 8)), (32, 1, (1, 2, 4, 8)), (64, 1, (2,)), (3, 1, (1, 8)),
+                                       (7, 1, (4, 1, 256)), (5, 1, (1, 2, 4, 8, 3, 5, 6, 15)), (12, 1, (8, 1, 4))])
 def test_render_expanded_matches_oracle(G, E, cmask):
     """Specialised shapes, the generic kernel, ragged C*S*S, and the shapes too large for the LDS table."""
     abi = importlib.import_module("gym-lmaze_amd._abi")

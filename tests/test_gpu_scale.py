@@ -273,7 +273,8 @@ def test_foveal_captured_autoreset_steps(variant):
         assert (eager.obs.view(torch.int32) == graphed.obs.view(torch.int32)).all(), rep
 
 
-@pytest.mark.parametrize("G,E,cmask", [(11, 7, (1, 2, 4, 8)), (12, 7, (1, 2, 4, 8)), (18, 4, (8, 1, 4)), (32, 7, (1, 2, 4, 8))])
+@pytest.mark.parametrize("G,E,cmask", [(11, 7, (1, 2, 4, 8)), (12, 7, (1, 2, 4, 8)), (18, 4, (8, 1, 4)), (32, 7, (1, 2, 4, 8)),
+                                       (11, 1, (1, 2, 4, 8)), (18, 1, (8, 1, 4)), (9, 1, (1,))])
 def test_render_expanded_streaming_regime(G, E, cmask):
     """Outputs beyond 192 MiB take the non-temporal, occupancy-capped launch: same floats as the definition
     out[i,c,x*E+xx,y*E+yy] = (obs[i,x,y] & mask[c]) != 0, written here with torch ops."""
@@ -287,10 +288,11 @@ def test_render_expanded_streaming_regime(G, E, cmask):
     assert abi.lib.lmaze_render_expanded(obs.data_ptr(), G, E, m, len(cmask), out.data_ptr(), N,
                                          torch.cuda.current_stream().cuda_stream) == 0
     masks = torch.tensor(cmask, dtype=torch.int32, device="cuda")[None, :, None, None]
-    for lo in range(0, N, 256):                                        # in slices: the torch expression is memory-hungry
-        want = ((obs[lo:lo + 256, None] & masks) != 0).to(torch.float32)
+    step = 256 if E > 1 else 16384
+    for lo in range(0, N, step):                                       # in slices: the torch expression is memory-hungry
+        want = ((obs[lo:lo + step, None] & masks) != 0).to(torch.float32)
         want = want.repeat_interleave(E, dim=2).repeat_interleave(E, dim=3)
-        assert torch.equal(out[lo:lo + 256], want), lo
+        assert torch.equal(out[lo:lo + step], want), lo
 
 
 @pytest.mark.parametrize("Cn", [4, 5, 7])

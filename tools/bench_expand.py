@@ -16,7 +16,9 @@ def main():
     abi = pkg._abi
     st = torch.cuda.current_stream().cuda_stream
     for (N, G, E, masks) in ((65536, 12, 7, (1, 2, 4, 8)), (65536, 11, 7, (1, 2, 4, 8)), (65536, 18, 4, (8, 1, 4)),
-                             (16384, 32, 7, (1, 2, 4, 8))):
+                             (16384, 32, 7, (1, 2, 4, 8)),
+                             # x1: the unexpanded float planes a policy network takes (LmazeVecEnv.planes())
+                             (1 << 20, 11, 1, (1, 2, 4, 8)), (1 << 20, 8, 1, (1, 2, 4, 8)), (1 << 18, 32, 1, (1, 2, 4, 8))):
         obs = torch.randint(0, 16, (N, G, G), dtype=torch.int32, device="cuda")
         out = torch.empty((N, len(masks), G * E, G * E), dtype=torch.float32, device="cuda")
         m = (C.c_int32 * len(masks))(*masks)
