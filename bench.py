@@ -66,6 +66,43 @@ def cpu_baseline(G, layout_codes, budget_s=12.0):
                       % (N, steps, G, G, threads, dt)}
 
 
+# algorithmic HBM bytes per env-step of the foveal variants: per-env scalars read + written,
+# the float32 [C,5,5] observation written, and for v4 the 18x18 float32 visit map read + written
+FOVEAL_BYTES = {"v1": 28 + 26 + 400, "v2": 28 + 17 + 500, "v4": 28 + 17 + 2 * 1296 + 700}
+FOVEAL_ACTIONS = {"v1": 4, "v2": 25, "v4": 25}
+
+
+def cpu_baseline_foveal(variant, budget_s=12.0):
+    """The C oracle's foveal step on this box's host cores, bounded sample of the same workload."""
+    import numpy as np
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import oracle_lib as O
+    pkg = importlib.import_module("gym-lmaze_amd")
+    vid = {"v1": O.VARIANT_V1, "v2": O.VARIANT_V2, "v4": O.VARIANT_V4}[variant]
+    tabs = [pkg.layouts.to_codes(t) for t in ((pkg.layouts.V1_GRID_14,) if variant == "v1" else pkg.layouts.FOVEAL_GRIDS_18)]
+    layouts = np.ascontiguousarray(np.stack(tabs))
+    G, N = layouts.shape[-1], 1 << 17
+    p = O.foveal_params(vid, G, len(tabs))
+    st = O.FovealState(vid, N, G)
+    threads = max(1, min(16, len(os.sched_getaffinity(0))))
+    O.set_threads(threads)
+    O.foveal_reset(p, layouts, None, 1, 1, 0, st)
+    rs = np.random.RandomState(1)
+    acts = [rs.randint(0, FOVEAL_ACTIONS[variant], N).astype(np.int32) for _ in range(8)]
+    O.foveal_step(p, layouts, acts[0], st)
+    t0 = time.perf_counter()
+    O.foveal_step(p, layouts, acts[1], st)
+    one = max(time.perf_counter() - t0, 1e-6)
+    steps = int(max(4, min(20000, budget_s / one)))
+    t0 = time.perf_counter()
+    for t in range(steps):
+        O.foveal_step(p, layouts, acts[t & 7], st)
+    dt = time.perf_counter() - t0
+    return {"value": N * steps / dt, "unit": "env-steps/s", "cores": threads, "kind": "port",
+            "sample": "%d envs x %d steps of the same lmaze-%s workload, C oracle (OpenMP, %d threads), %.1f s"
+                      % (N, steps, variant, threads, dt)}
+
+
 def measured_ceiling(pkg, nbytes, dev, reps=20):
     """The box's own write / copy ceilings: lmaze_bandwidth_probe over a scratch buffer the size
     of the obs buffer, events on the launch stream.  Reported beside the 8 TB/s peak, never instead of it."""
@@ -94,9 +131,10 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=300)
     ap.add_argument("--warmup", type=int, default=30)
-    ap.add_argument("--workload", choices=["c3", "c2", "c5"], default="c3",
+    ap.add_argument("--workload", choices=["c3", "c2", "c5", "v1", "v2", "v4"], default="c3",
                     help="c3 (default, the metric's config): 1 048 576 x 11x11 shared layout; "
-                         "c2: 65 536 x 8x8; c5: 1 048 576 x 32x32 with per-env random layouts")
+                         "c2: 65 536 x 8x8; c5: 1 048 576 x 32x32 with per-env random layouts; "
+                         "v1 / v2 / v4: 1 048 576 envs of the foveal variants (5x5 window observations; SURVEY 8(f)3)")
     ap.add_argument("--envs", type=int, default=None, help="envs per GPU (overrides the workload's)")
     ap.add_argument("--grid", type=int, default=None)
     ap.add_argument("--per-env-layouts", action="store_true", help="own random maze per env")
@@ -116,7 +154,11 @@ def main():
     import numpy as np
     import torch
 
-    preset = {"c3": (1 << 20, 11, False), "c2": (65536, 8, False), "c5": (1 << 20, 32, True)}[args.workload]
+    foveal = args.workload in FOVEAL_BYTES
+    preset = {"c3": (1 << 20, 11, False), "c2": (65536, 8, False), "c5": (1 << 20, 32, True),
+              "v1": (1 << 20, 14, False), "v2": (1 << 20, 18, False), "v4": (1 << 20, 18, False)}[args.workload]
+    if foveal and (args.graph or args.per_env_layouts or args.grid is not None):
+        raise SystemExit("--graph / --per-env-layouts / --grid do not apply to the foveal workloads")
     args.envs = args.envs if args.envs is not None else preset[0]
     args.grid = args.grid if args.grid is not None else preset[1]
     args.per_env_layouts = args.per_env_layouts or preset[2]
@@ -162,37 +204,54 @@ def main():
     pkg = importlib.import_module("gym-lmaze_amd")
     G, N = args.grid, args.envs
     env_base = rank * N
-    if args.workload == "c2":
-        layout = pkg.layouts.to_codes(pkg.layouts.GRID_8_BORDERED)   # lmaze_env.py:28-35 literal, bordered
-    else:
-        layout = pkg.layouts.to_codes(pkg.layouts.open_room(G, (G // 2, G // 2)))
-    if args.per_env_layouts:
-        gen = torch.Generator(device=dev).manual_seed(7 + rank)
-        lay = torch.where(torch.rand((N, G, G), device=dev, generator=gen) < 0.25, ord("W"), ord("B")).to(torch.uint8)
-        lay[:, 0, :] = ord("W"); lay[:, -1, :] = ord("W"); lay[:, :, 0] = ord("W"); lay[:, :, -1] = ord("W")
-        lay[:, 1, 1] = ord("S")
-        lay[:, G - 2, G - 2] = ord("X")
-        env = pkg.LmazeVecEnv(N, variant="v0", per_env_layouts=lay, device=dev, seed=1, env_base=env_base)
-        workload = "%d x %dx%d mazes per GPU, v0 rules, per-env random layouts (p_wall 0.25), compact int32 obs" % (N, G, G)
-    else:
-        env = pkg.LmazeVecEnv(N, variant="v0", layout=layout, device=dev, seed=1, env_base=env_base)
-        workload = "%d x %dx%d mazes per GPU, v0 rules, shared open-room layout, compact int32 obs" % (N, G, G)
-
-    tuned = None
-    if args.launch_hint is not None:
-        env.params.launch_hint = args.launch_hint
-    elif not args.no_autotune:
-        tuned = env.autotune(auto_reset=args.auto_reset)     # untimed: picks workgroups-per-CU for this shape/device
-    gen = torch.Generator(device=dev).manual_seed(1 + rank)      # torch's device generator is Philox
+    tuned, layout = None, None
     R = args.action_rows
-    actions = torch.randint(0, 4, (R, N), dtype=torch.int32, device=dev, generator=gen)
-    row_ptr = [actions[r].data_ptr() for r in range(R)]
+    gen = torch.Generator(device=dev).manual_seed(1 + rank)      # torch's device generator is Philox
+    if foveal:
+        variant = args.workload
+        env = pkg.LmazeFovealVecEnv(N, variant=variant, device=dev, seed=1, env_base=env_base)
+        G = env.grid
+        if variant == "v1":        # the two-level loop's upper half: a foveal goal per env (lmaze_env_v1.py:104-110)
+            env.set_foveal_goal(torch.randint(0, 5, (N, 2), dtype=torch.int32, device=dev, generator=gen))
+        workload = ("%d x lmaze-%s per GPU (%dx%d layouts, 5x5 window, float32 [%d,5,5] observation%s)"
+                    % (N, variant, G, G, env.channels, ", float32 visit map" if variant == "v4" else ""))
+        actions = torch.randint(0, FOVEAL_ACTIONS[variant], (R, N), dtype=torch.int32, device=dev, generator=gen)
+        # warm the device as LmazeVecEnv.autotune() does for the grid workloads (cold clocks)
+        for t in range(150):
+            env.step(actions[t % R], auto_reset=args.auto_reset)
 
-    def run(k0, k, captured=False):
-        for t in range(k0, k0 + k):
-            # under capture the reset epoch is a device word handed from launch to launch (slot = launch index)
-            env.step_raw(row_ptr[t % R], auto_reset=args.auto_reset,
-                         epoch_slot=(t - k0) if (captured and args.auto_reset) else None)
+        def run(k0, k, captured=False):
+            for t in range(k0, k0 + k):
+                env.step(actions[t % R], auto_reset=args.auto_reset)
+    else:
+        if args.workload == "c2":
+            layout = pkg.layouts.to_codes(pkg.layouts.GRID_8_BORDERED)   # lmaze_env.py:28-35 literal, bordered
+        else:
+            layout = pkg.layouts.to_codes(pkg.layouts.open_room(G, (G // 2, G // 2)))
+        if args.per_env_layouts:
+            lgen = torch.Generator(device=dev).manual_seed(7 + rank)
+            lay = torch.where(torch.rand((N, G, G), device=dev, generator=lgen) < 0.25, ord("W"), ord("B")).to(torch.uint8)
+            lay[:, 0, :] = ord("W"); lay[:, -1, :] = ord("W"); lay[:, :, 0] = ord("W"); lay[:, :, -1] = ord("W")
+            lay[:, 1, 1] = ord("S")
+            lay[:, G - 2, G - 2] = ord("X")
+            env = pkg.LmazeVecEnv(N, variant="v0", per_env_layouts=lay, device=dev, seed=1, env_base=env_base)
+            workload = "%d x %dx%d mazes per GPU, v0 rules, per-env random layouts (p_wall 0.25), compact int32 obs" % (N, G, G)
+        else:
+            env = pkg.LmazeVecEnv(N, variant="v0", layout=layout, device=dev, seed=1, env_base=env_base)
+            workload = "%d x %dx%d mazes per GPU, v0 rules, shared open-room layout, compact int32 obs" % (N, G, G)
+
+        if args.launch_hint is not None:
+            env.params.launch_hint = args.launch_hint
+        elif not args.no_autotune:
+            tuned = env.autotune(auto_reset=args.auto_reset)     # untimed: picks workgroups-per-CU for this shape/device
+        actions = torch.randint(0, 4, (R, N), dtype=torch.int32, device=dev, generator=gen)
+        row_ptr = [actions[r].data_ptr() for r in range(R)]
+
+        def run(k0, k, captured=False):
+            for t in range(k0, k0 + k):
+                # under capture the reset epoch is a device word handed from launch to launch (slot = launch index)
+                env.step_raw(row_ptr[t % R], auto_reset=args.auto_reset,
+                             epoch_slot=(t - k0) if (captured and args.auto_reset) else None)
 
     with torch.cuda.device(dev):
         run(0, args.warmup)
@@ -230,7 +289,10 @@ def main():
     kern_ms = float(ev0.elapsed_time(ev1) / args.steps)   # ms per launch, launch gaps included
 
     # sanity: the run really stepped (every env advanced warmup+steps times)
-    if not args.auto_reset:
+    if foveal:      # like the reference, stepping goes on past `done` unless the reset is fused in
+        top = int(env.step_count.max().item())
+        assert top >= 1 and (not args.auto_reset or top <= env.params.step_limit + 1)
+    elif not args.auto_reset:
         assert int(env.step_count.min().item()) == args.warmup + args.steps
     else:  # episodes restart: nobody is past the step limit, and everybody moved
         assert 1 <= int(env.step_count.min().item()) and int(env.step_count.max().item()) <= env.step_limit
@@ -238,13 +300,13 @@ def main():
     ceiling = measured_ceiling(pkg, env.obs.numel() * 4, dev) if rank == 0 else None
 
     if rank == 0:
-        B = bytes_per_env_step(G, args.per_env_layouts)
+        B = FOVEAL_BYTES[args.workload] if foveal else bytes_per_env_step(G, args.per_env_layouts)
         total_steps = world * N * args.steps
         value = total_steps / elapsed
         achieved = N * B / (kern_ms * 1e-3) / 1e9
         traffic = None
         tpath = os.path.join(ROOT, "profiles", "traffic.json")
-        if os.path.exists(tpath):
+        if os.path.exists(tpath) and not foveal:
             try:
                 tj = json.load(open(tpath))
                 key = "g%d_%s" % (G, "perenv" if args.per_env_layouts else "shared")
@@ -259,22 +321,24 @@ def main():
             "workload_id": args.workload,
             "value": value, "unit": "env-steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "int32", "data": "synthetic",
+            "vs_baseline": None, "dtype": "f32" if foveal else "int32", "data": "synthetic",
             "config": {"workload": workload, "envs_per_gpu": N, "grid": G, "global_envs": world * N,
                        "parallelism": "independent env shards, no collective on the step path",
-                       "actions": "uniform{0..3} int32[%d,N] ring, torch Philox seed 1+rank" % R,
+                       "actions": "uniform{0..%d} int32[%d,N] ring, torch Philox seed 1+rank"
+                                  % ((FOVEAL_ACTIONS[args.workload] if foveal else 4) - 1, R),
                        "auto_reset": bool(args.auto_reset), "hip_graph": bool(args.graph),
                        "collective_backend": ("rccl" if backend == "nccl" else backend + " (REHEARSAL, ranks share a GPU)")
                        if dist is not None else None,
-                       "launch_hint": int(env.params.launch_hint),
+                       "launch_hint": None if foveal else int(env.params.launch_hint),
                        "autotune_ms": {str(k): round(v, 5) for k, v in (tuned or {}).items()}},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "kernel": "lmaze::step_%s_kernel<%d, v0>" % ("perenv" if args.per_env_layouts else "shared", G),
+                         "kernel": ("lmaze::foveal_kernel<%s, FM_STEP>" % args.workload) if foveal else
+                                   "lmaze::step_%s_kernel<%d, v0>" % ("perenv" if args.per_env_layouts else "shared", G),
                          "bytes_per_env_step": B, "kernel_ms_avg": kern_ms, "measured_ceiling": ceiling},
         }
         if not args.no_cpu_baseline and world == 1:      # rank 0 at N=1 only
-            out["cpu_baseline"] = cpu_baseline(G, layout)
+            out["cpu_baseline"] = cpu_baseline_foveal(args.workload) if foveal else cpu_baseline(G, layout)
         print(json.dumps(out))
     if dist is not None:
         dist.destroy_process_group()

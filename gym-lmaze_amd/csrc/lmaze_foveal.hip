@@ -774,7 +774,9 @@ static hipError_t launch_foveal_mode(const FovealArgs& a, hipStream_t s) {
         // envs per workgroup, measured warm at 1M envs (TB/s of algorithmic traffic, 256 / 128 / 64 envs):
         //   v1 (400 B of observation per env)  5.9-6.0 / 6.1 / 6.7-6.8      v2 (500 B)  5.9 / 6.1 / 5.8
         case LMAZE_VARIANT_V1: return launch_foveal_one<LMAZE_VARIANT_V1, MODE, 64>(a, s);
-        case LMAZE_VARIANT_V2: return launch_foveal_one<LMAZE_VARIANT_V2, MODE, 128>(a, s);
+        case LMAZE_VARIANT_V2:
+            if (MODE == FM_STEP && a.auto_reset) return launch_foveal_one<LMAZE_VARIANT_V2, MODE, 256>(a, s);
+            return launch_foveal_one<LMAZE_VARIANT_V2, MODE, 128>(a, s);
         case LMAZE_VARIANT_V5:
         case LMAZE_VARIANT_V6:
             return launch_foveal_one<LMAZE_VARIANT_V5, MODE, 64>(a, s);
