@@ -56,6 +56,9 @@ struct EnvRec {           // one env after its transition (registers only; phase
 // ranked in row-major order (the order of the reference's own scan over the grid).
 __device__ __forceinline__ int mask_count(const uint64_t* rows, int G) {
     int cnt = 0;
+    // not unrolled: with G known at compile time the unrolled loops keep a whole layout's row masks live and
+    // the fused-reset instantiation then needs 115 VGPRs (4 waves per SIMD instead of 7) for the whole kernel
+#pragma unroll 1
     for (int x = 1; x <= G - 2; ++x) cnt += __popcll(rows[x]);
     return cnt;
 }
@@ -63,6 +66,7 @@ __device__ __forceinline__ int mask_count(const uint64_t* rows, int G) {
 // rank of cell (gx, gy) among the accepted cells (number of accepted cells before it)
 __device__ __forceinline__ int mask_rank(const uint64_t* rows, int G, int gx, int gy) {
     int cnt = 0;
+#pragma unroll 1
     for (int x = 1; x < gx && x <= G - 2; ++x) cnt += __popcll(rows[x]);
     if (gx >= 1 && gx <= G - 2) cnt += __popcll(rows[gx] & ((1ull << gy) - 1ull));
     return cnt;
@@ -70,6 +74,7 @@ __device__ __forceinline__ int mask_rank(const uint64_t* rows, int G, int gx, in
 
 // k-th accepted cell (0-based) as x*G + y, or -1
 __device__ __forceinline__ int mask_kth(const uint64_t* rows, int G, int k) {
+#pragma unroll 1
     for (int x = 1; x <= G - 2; ++x) {
         uint64_t m = rows[x];
         const int c = __popcll(m);
@@ -497,8 +502,11 @@ __global__ __launch_bounds__(LMAZE_BLOCK) void foveal_kernel(const FovealArgs a)
                 const int cx = cen[le * 4], cy = cen[le * 4 + 1];
                 const bool fresh = MODE == FM_STEP && AR && (fl & 4), nostep = MODE == FM_STEP && AR && (fl & 8);
                 float4 v = make_float4(0.f, 0.f, 0.f, 0.f);                 // reset: v4:112 / v5:130
-                if (MODE == FM_STEP && !fresh) v = reinterpret_cast<const float4*>(vis)[q];
+                // STEP loads unconditionally (a load that waits on the per-env flag does not pipeline: the fused
+                // instantiation ran 40 % behind the plain one); the few freshly reset maps drop what they read
+                if (MODE == FM_STEP) v = reinterpret_cast<const float4*>(vis)[q];
                 if (fresh) {                                                // fused reset: v4:112-119 at the placed ball
+                    v = make_float4(0.f, 0.f, 0.f, 0.f);
                     const int rx = rcen[le * 2], ry = rcen[le * 2 + 1];
                     v.x = update(v.x, c0, rx, ry);
                     v.y = update(v.y, c0 + 1, rx, ry);
