@@ -306,10 +306,10 @@ def main():
         achieved = N * B / (kern_ms * 1e-3) / 1e9
         traffic = None
         tpath = os.path.join(ROOT, "profiles", "traffic.json")
-        if os.path.exists(tpath) and not foveal:
+        if os.path.exists(tpath):
             try:
                 tj = json.load(open(tpath))
-                key = "g%d_%s" % (G, "perenv" if args.per_env_layouts else "shared")
+                key = args.workload if foveal else "g%d_%s" % (G, "perenv" if args.per_env_layouts else "shared")
                 rec = tj.get(key, {})
                 # the PMC passes profiled one launch shape: only quote them for that shape
                 if rec.get("algorithmic_bytes_per_launch") == N * B:
