@@ -74,6 +74,8 @@ void run_grid(int64_t N, int rounds, int iters, hipStream_t s) {
     };
     add(true, 8, 0, 0); add(true, 5, 0, 0); add(true, 4, 0, 0); add(true, 3, 0, 0); add(true, 2, 0, 0);
     vs.push_back({"fill one-store-per-thread", [=](hipStream_t st) { hipLaunchKernelGGL(fill_kernel<false>, dim3((unsigned)((n16 + 255) / 256)), dim3(256), 0, st, (int4*)d_obs, n16, 3); }, {}});
+    vs.push_back({"fill one-store-per-thread, non-temporal", [=](hipStream_t st) { hipLaunchKernelGGL(fill_kernel<true>, dim3((unsigned)((n16 + 255) / 256)), dim3(256), 0, st, (int4*)d_obs, n16, 3); }, {}});
+    vs.push_back({"fill chunk-per-workgroup, non-temporal, 3 wg/CU", [=](hipStream_t st) { const int ch = EPB * CELLS / 4; hipLaunchKernelGGL(fill_chunk_kernel<true>, dim3((unsigned)((n16 + ch - 1) / ch)), dim3(256), lds_for_workgroups_per_cu(3), st, (int4*)d_obs, ch, n16, 3); }, {}});
     vs.push_back({"fill chunk-per-workgroup", [=](hipStream_t st) { const int ch = EPB * CELLS / 4; hipLaunchKernelGGL(fill_chunk_kernel<false>, dim3((unsigned)((n16 + ch - 1) / ch)), dim3(256), 0, st, (int4*)d_obs, ch, n16, 3); }, {}});
     vs.push_back({"hipMemsetAsync", [=](hipStream_t st) { (void)hipMemsetAsync(d_obs, 1, n16 * 16, st); }, {}});
 
@@ -112,6 +114,7 @@ int main(int argc, char** argv) {
     // CU -- 64 x 3 = 79 us, 48 x 4 = 80 us, 96 x 2 = 89 us -- and the chunk must be a multiple of 64 B
     // (56 or 72 envs of 484 B are only 32-B aligned: 108-124 us)
     run_grid<11, 64>(1 << 20, rounds, iters, s);
+    if (argc > 3) return 0;   // any third argument: the metric's shape only
     run_grid<11, 48>(1 << 20, rounds, iters, s);
     run_grid<11, 96>(1 << 20, rounds, iters, s);
     run_grid<8, 128>(1 << 21, rounds, iters, s);
