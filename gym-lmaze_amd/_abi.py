@@ -14,7 +14,7 @@ import os
 import torch  # noqa: F401
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "liblmaze_hip.so")
+LIB_PATH = os.environ.get("LMAZE_HIP_LIB") or os.path.join(HERE, "liblmaze_hip.so")   # override: another build of the same ABI
 
 ABI_VERSION = 2
 VARIANT_V0, VARIANT_V3 = 0, 3

@@ -565,10 +565,23 @@ __global__ __launch_bounds__(LMAZE_BLOCK) void foveal_kernel(const FovealArgs a)
         int le = f / PERENV;
         int rem = f - le * PERENV;
         float v[4];
+        if (!V4) {
+            // bit planes only (v1, v2): the four floats sit in one 25-cell plane or run into the next one (the
+            // next channel, or channel 0 of the next env): two plane masks, one 32-bit shift per float
+            const int ch0 = rem / W25, cell0 = rem - ch0 * W25;
+            const bool wrap = ch0 + 1 == C;
+            const uint32_t m0 = masks[le * 8 + ch0], m1 = masks[(wrap ? le + 1 : le) * 8 + (wrap ? 0 : ch0 + 1)];
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            v[k] = element(le, rem);
-            if (++rem == PERENV) { rem = 0; ++le; }
+            for (int k = 0; k < 4; ++k) {
+                const int c = cell0 + k;
+                v[k] = ((c < W25 ? (m0 >> c) : (m1 >> (c - W25))) & 1u) ? 1.0f : 0.0f;
+            }
+        } else {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                v[k] = element(le, rem);
+                if (++rem == PERENV) { rem = 0; ++le; }
+            }
         }
         if (a.nt) {  // large batches: the observation cannot stay in the Infinity Cache, stream it (+6...12 %)
             typedef float v4f __attribute__((ext_vector_type(4)));
