@@ -305,3 +305,46 @@ def test_expand_planes_streaming_regime(Cn):
                                        torch.cuda.current_stream().cuda_stream) == 0
     want = planes.repeat_interleave(7, dim=2).repeat_interleave(7, dim=3)
     assert torch.equal(out.view(torch.int32), want.view(torch.int32))
+
+
+@pytest.mark.parametrize("variant,shared,G", [("v0", True, 11), ("v3", True, 12), ("v0", False, 32), ("v3", False, 9)])
+def test_long_rollout_with_fused_resets_against_the_oracle(variant, shared, G):
+    """3 000 steps (dozens of episodes per env) of the fused auto-reset path against the oracle doing
+    reset(mask=done) + step with the same Philox draws; compared every 100 steps and at the end."""
+    from helpers import bordered_random_layouts
+    N, T, seed, base = 2048, 3000, 5, 123456789
+    if shared:
+        lay = bordered_random_layouts(1, G, 900 + G)[0]
+        env = PKG.LmazeVecEnv(N, variant=variant, layout=lay, seed=seed, env_base=base)
+        mode = O.LAYOUT_SHARED
+    else:
+        lay = bordered_random_layouts(N, G, 900 + G)
+        env = PKG.LmazeVecEnv(N, variant=variant, per_env_layouts=lay, seed=seed, env_base=base)
+        mode = O.LAYOUT_PER_ENV
+    vid = O.VARIANT_V3 if variant == "v3" else O.VARIANT_V0
+    p = O.params(vid, G, mode, env.step_limit, *env.rewards)
+    st = {k: np.array(v, copy=True) for k, v in env.host_state().items()}
+    layc = np.ascontiguousarray(lay)
+    ref = np.zeros((N, G, G), np.int32)
+    acts = torch.randint(-1, 5, (T, N), dtype=torch.int32, device="cuda")     # some no-op ids among them
+    acts_h = acts.cpu().numpy()
+    epoch = env._epoch
+    goal = st["goal_xy"] if variant == "v3" else None
+    episodes = 0
+    for t in range(T):
+        env.step(acts[t], auto_reset=True)
+        mask = np.ascontiguousarray(st["done"])
+        episodes += int(mask.sum())
+        O.reset(p, layc, mask, seed, epoch + t, st["ball_xy"], goal, st["step_count"], st["reward"], st["done"], None,
+                env_base=base)
+        if variant == "v3":
+            O.step_v3(p, layc, acts_h[t], st["ball_xy"], st["goal_xy"], st["step_count"], st["reward"], st["done"], ref)
+        else:
+            O.step_v0(p, layc, acts_h[t], st["ball_xy"], st["step_count"], st["reward"], st["done"], st["goal_count"], ref)
+        if t % 100 == 99 or t == T - 1:
+            h = env.host_state()
+            for k in ("ball_xy", "goal_xy", "step_count", "done") + (("goal_count",) if variant == "v0" else ()):
+                assert (h[k] == st[k]).all(), (k, t)
+            assert (f32_bits(h["reward"]) == f32_bits(st["reward"])).all(), t
+            assert (_np(env.obs) == ref).all(), t
+    assert episodes > 20 * N
