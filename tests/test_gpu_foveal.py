@@ -441,3 +441,28 @@ def test_foveal_episode_stats(variant):
     goal = np.float32(env.params.reward_goal)
     assert st["done"] == int(h["done"].sum()) and st["goal_rewards"] == int((h["reward"] == goal).sum())
     assert st["done_steps"] == int(h["step_count"][h["done"] != 0].sum()) and st["done"] > 0
+
+
+@pytest.mark.parametrize("variant", ["v2", "v4"])
+def test_long_fused_rollout_against_the_oracle(variant):
+    """1 500 steps (about 30 episodes per env; the v4 visit maps are halved and re-summed every step) of the
+    fused auto-reset path against the oracle doing reset(mask=done) + step on the same Philox draws."""
+    N, T, seed, base = 1024, 1500, 17, 987654321
+    env = PKG.LmazeFovealVecEnv(N, variant=variant, seed=seed, env_base=base)
+    lay = _np(env.layouts)
+    p = O.foveal_params(VID[variant], env.grid, env.n_layouts)
+    st = O.FovealState(VID[variant], N, env.grid)
+    O.foveal_reset(p, lay, None, 1, seed, 0, st, env_base=base)
+    _assert_same(env, st, variant, "reset")
+    acts = torch.randint(0, 25, (T, N), dtype=torch.int32, device="cuda")
+    acts_h = acts.cpu().numpy()
+    epoch, episodes = env._epoch, 0
+    for t in range(T):
+        env.step(acts[t], auto_reset=True)
+        m = st.done.copy()
+        episodes += int(m.sum())
+        O.foveal_reset(p, lay, m, 1, seed, epoch + t, st, env_base=base)
+        O.foveal_step(p, lay, acts_h[t], st)
+        if t % 50 == 49 or t == T - 1:
+            _assert_same(env, st, variant, t)
+    assert episodes > 20 * N
