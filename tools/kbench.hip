@@ -72,7 +72,8 @@ void run_grid(int64_t N, int rounds, int iters, hipStream_t s) {
             else hipLaunchKernelGGL((step_shared_kernel<G, LMAZE_VARIANT_V0, true, EPB, false>), dim3(blocks), dim3(256), lds, st, b);
         }, {}});
     };
-    add(true, 8, 0, 0); add(true, 5, 0, 0); add(true, 4, 0, 0); add(true, 3, 0, 0); add(true, 2, 0, 0);
+    if (N <= (1 << 17)) { add(false, 8, 0, 0); add(true, 8, 0, 0); }   // launch-bound sizes: plain stores, no cap
+    else { add(true, 8, 0, 0); add(true, 5, 0, 0); add(true, 4, 0, 0); add(true, 3, 0, 0); add(true, 2, 0, 0); }
     vs.push_back({"fill one-store-per-thread", [=](hipStream_t st) { hipLaunchKernelGGL(fill_kernel<false>, dim3((unsigned)((n16 + 255) / 256)), dim3(256), 0, st, (int4*)d_obs, n16, 3); }, {}});
     vs.push_back({"fill one-store-per-thread, non-temporal", [=](hipStream_t st) { hipLaunchKernelGGL(fill_kernel<true>, dim3((unsigned)((n16 + 255) / 256)), dim3(256), 0, st, (int4*)d_obs, n16, 3); }, {}});
     vs.push_back({"fill chunk-per-workgroup, non-temporal, 3 wg/CU", [=](hipStream_t st) { const int ch = EPB * CELLS / 4; hipLaunchKernelGGL(fill_chunk_kernel<true>, dim3((unsigned)((n16 + ch - 1) / ch)), dim3(256), lds_for_workgroups_per_cu(3), st, (int4*)d_obs, ch, n16, 3); }, {}});
@@ -114,7 +115,14 @@ int main(int argc, char** argv) {
     // CU -- 64 x 3 = 79 us, 48 x 4 = 80 us, 96 x 2 = 89 us -- and the chunk must be a multiple of 64 B
     // (56 or 72 envs of 484 B are only 32-B aligned: 108-124 us)
     run_grid<11, 64>(1 << 20, rounds, iters, s);
-    if (argc > 3) return 0;   // any third argument: the metric's shape only
+    if (argc > 3 && argv[3][0] == 'c') {   // "c2": the launch-bound configuration, envs per workgroup
+        run_grid<8, 128>(65536, rounds, iters, s);
+        run_grid<8, 64>(65536, rounds, iters, s);
+        run_grid<8, 32>(65536, rounds, iters, s);
+        run_grid<8, 16>(65536, rounds, iters, s);
+        return 0;
+    }
+    if (argc > 3) return 0;   // any other third argument: the metric's shape only
     run_grid<11, 48>(1 << 20, rounds, iters, s);
     run_grid<11, 96>(1 << 20, rounds, iters, s);
     run_grid<8, 128>(1 << 21, rounds, iters, s);
