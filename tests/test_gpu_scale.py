@@ -348,3 +348,40 @@ def test_long_rollout_with_fused_resets_against_the_oracle(variant, shared, G):
             assert (f32_bits(h["reward"]) == f32_bits(st["reward"])).all(), t
             assert (_np(env.obs) == ref).all(), t
     assert episodes > 20 * N
+
+
+def test_c4_whole_batch_on_one_gpu_8m_envs():
+    """BASELINE configs[3] is 8 388 608 x 11x11 over eight GPUs; all of it also fits one MI355X (4.1 GB of
+    planes).  Past 2^31 bytes of observation the index arithmetic has to be 64-bit everywhere: invariants on
+    every env, and the tail of the batch against the oracle (the last 4 096 envs, same global ids)."""
+    N, G, T = 1 << 23, 11, 6
+    lay = L.to_codes(L.open_room(G, (5, 5)))
+    env = PKG.LmazeVecEnv(N, variant="v0", layout=lay, seed=9)
+    tail = slice(N - 4096, N)
+    st = {k: np.array(v[tail], copy=True) for k, v in env.host_state().items()}
+    p = O.params(O.VARIANT_V0, G, O.LAYOUT_SHARED)
+    ref = np.zeros((4096, G, G), np.int32)
+    gen = torch.Generator(device="cuda").manual_seed(3)
+    for t in range(T):
+        a = torch.randint(0, 4, (N,), dtype=torch.int32, device="cuda", generator=gen)
+        env.step(a, auto_reset=(t >= 3))
+        a_tail = np.ascontiguousarray(_np(a[tail]))
+        if t >= 3:   # nobody is done after 3 steps of a 100-step episode unless the goal was hit
+            O.reset(p, lay, np.ascontiguousarray(st["done"]), 9, env._epoch - 1, st["ball_xy"], None, st["step_count"],
+                    st["reward"], st["done"], None, env_base=N - 4096)
+        O.step_v0(p, lay, a_tail, st["ball_xy"], st["step_count"], st["reward"], st["done"], st["goal_count"], ref)
+    assert (_np(env.obs[tail]) == ref).all() and (_np(env.ball_xy[tail]) == st["ball_xy"]).all()
+    bits = torch.from_numpy(np.vectorize(lambda c: {ord("W"): 2, ord("X"): 4, ord("B"): 8}.get(c, 0))(lay).astype(np.int32)).cuda()
+    for lo in range(0, N, 1 << 21):                                  # in slices: the checks allocate temporaries
+        sl = slice(lo, lo + (1 << 21))
+        obs = env.obs[sl]
+        ball = obs & 1
+        assert bool((ball.flatten(1).sum(dim=1) == 1).all())
+        idx = env.ball_xy[sl, 0].long() * G + env.ball_xy[sl, 1].long()
+        assert bool((ball.flatten(1).gather(1, idx[:, None]) == 1).all())
+        assert bool(((obs & ~1) == bits).all())
+    out = env.planes()                                               # 16.2 GB of float planes: the x1 render past 2^32 bytes
+    want = ((env.obs[tail][:, None] & torch.tensor([1, 2, 4, 8], dtype=torch.int32, device="cuda")[None, :, None, None]) != 0)
+    assert torch.equal(out[tail], want.to(torch.float32))
+    assert torch.equal(out[:4096], ((env.obs[:4096][:, None] & torch.tensor([1, 2, 4, 8], dtype=torch.int32,
+                                                                           device="cuda")[None, :, None, None]) != 0).to(torch.float32))
