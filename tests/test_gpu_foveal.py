@@ -466,3 +466,35 @@ def test_long_fused_rollout_against_the_oracle(variant):
         if t % 50 == 49 or t == T - 1:
             _assert_same(env, st, variant, t)
     assert episodes > 20 * N
+
+
+def test_four_million_v4_envs_tail_against_the_oracle():
+    """5.4 GB of visit maps and 2.9 GB of observations: offsets past 2^32 bytes.  The last 2 048 envs of the
+    batch against the oracle, and the first 2 048 as well."""
+    N, K, T = 1 << 22, 2048, 5
+    env = PKG.LmazeFovealVecEnv(N, variant="v4", seed=21)
+    lay = _np(env.layouts)
+    p = O.foveal_params(O.VARIANT_V4, env.grid, env.n_layouts)
+    h = env.host_state()
+    mirrors = []
+    for sl in (slice(0, K), slice(N - K, N)):
+        st = O.FovealState(O.VARIANT_V4, K, env.grid)
+        for k in ("ball_xy", "goal_xy", "fgoal_xy", "layout_id", "step_count", "foveal_step_count", "reward",
+                  "foveal_reward", "done", "foveal_done"):
+            getattr(st, k)[...] = h[k][sl]
+        st.visit[...] = _np(env.visit[sl])
+        st.obs[...] = _np(env.obs[sl])
+        mirrors.append((sl, st))
+    gen = torch.Generator(device="cuda").manual_seed(4)
+    for t in range(T):
+        a = torch.randint(0, 25, (N,), dtype=torch.int32, device="cuda", generator=gen)
+        env.step(a)
+        for sl, st in mirrors:
+            O.foveal_step(p, lay, np.ascontiguousarray(_np(a[sl])), st)
+    h = env.host_state()
+    for sl, st in mirrors:
+        for k in ("ball_xy", "step_count", "done"):
+            assert (h[k][sl] == getattr(st, k)).all(), (k, sl)
+        assert (f32_bits(h["reward"][sl]) == f32_bits(st.reward)).all()
+        assert (_bits(_np(env.visit[sl])) == _bits(st.visit)).all()
+        assert (_bits(_np(env.obs[sl])) == _bits(st.obs)).all()
