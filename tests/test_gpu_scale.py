@@ -385,3 +385,29 @@ def test_c4_whole_batch_on_one_gpu_8m_envs():
     assert torch.equal(out[tail], want.to(torch.float32))
     assert torch.equal(out[:4096], ((env.obs[:4096][:, None] & torch.tensor([1, 2, 4, 8], dtype=torch.int32,
                                                                            device="cuda")[None, :, None, None]) != 0).to(torch.float32))
+
+
+def test_four_million_per_env_32x32_tail_against_the_oracle():
+    """17 GB of planes and 4 GB of per-env layouts on one GPU: the last and the first 1 024 envs against the
+    oracle (per-env kernel, one wave per env: the env index times 4 096 bytes passes 2^32 at env 2^20)."""
+    N, G, K, T = 1 << 22, 32, 1024, 4
+    gen = torch.Generator(device="cuda").manual_seed(11)
+    lay = torch.where(torch.rand((N, G, G), device="cuda", generator=gen) < 0.25, ord("W"), ord("B")).to(torch.uint8)
+    lay[:, 0, :] = ord("W"); lay[:, -1, :] = ord("W"); lay[:, :, 0] = ord("W"); lay[:, :, -1] = ord("W")
+    lay[:, 1, 1] = ord("S")
+    lay[:, G - 2, G - 2] = ord("X")
+    env = PKG.LmazeVecEnv(N, variant="v0", per_env_layouts=lay, seed=2, validate=False)
+    p = O.params(O.VARIANT_V0, G, O.LAYOUT_PER_ENV)
+    h = env.host_state()
+    mirrors = []
+    for sl in (slice(0, K), slice(N - K, N)):
+        st = {k: np.array(v[sl], copy=True) for k, v in h.items()}
+        mirrors.append((sl, st, np.ascontiguousarray(_np(lay[sl])), np.zeros((K, G, G), np.int32)))
+    for t in range(T):
+        a = torch.randint(0, 4, (N,), dtype=torch.int32, device="cuda", generator=gen)
+        env.step(a)
+        for sl, st, lay_np, ref in mirrors:
+            O.step_v0(p, lay_np, np.ascontiguousarray(_np(a[sl])), st["ball_xy"], st["step_count"], st["reward"],
+                      st["done"], st["goal_count"], ref)
+    for sl, st, lay_np, ref in mirrors:
+        assert (_np(env.obs[sl]) == ref).all() and (_np(env.ball_xy[sl]) == st["ball_xy"]).all(), sl
