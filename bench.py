@@ -148,7 +148,10 @@ def main():
                          "rocprofv3 passes so that every profiled launch runs the policy the bench line was measured with")
     ap.add_argument("--graph", action="store_true",
                     help="capture the K timed launches into one hipGraph and time its replay (launch-bound sizes)")
-    ap.add_argument("--action-rows", type=int, default=32, help="distinct pre-generated action rows (ring)")
+    ap.add_argument("--action-rows", type=int, default=None,
+                    help="rows of the pre-generated action tensor int32[rows, N] (default: one per timed step, the "
+                         "[T,N] tensor of SURVEY 8(d) C3, capped at 1024 rows; fewer rows are cycled -- 32 rows of "
+                         "1M envs are 134 MB and stay in the Infinity Cache, which flatters the step kernel)")
     args = ap.parse_args()
 
     import numpy as np
@@ -205,7 +208,7 @@ def main():
     G, N = args.grid, args.envs
     env_base = rank * N
     tuned, layout = None, None
-    R = args.action_rows
+    R = args.action_rows if args.action_rows else max(1, min(args.steps, 1024))
     gen = torch.Generator(device=dev).manual_seed(1 + rank)      # torch's device generator is Philox
     if foveal:
         variant = args.workload
@@ -240,12 +243,14 @@ def main():
             env = pkg.LmazeVecEnv(N, variant="v0", layout=layout, device=dev, seed=1, env_base=env_base)
             workload = "%d x %dx%d mazes per GPU, v0 rules, shared open-room layout, compact int32 obs" % (N, G, G)
 
+        actions = torch.randint(0, 4, (R, N), dtype=torch.int32, device=dev, generator=gen)
+        row_ptr = [actions[r].data_ptr() for r in range(R)]
         if args.launch_hint is not None:
             env.params.launch_hint = args.launch_hint
         elif not args.no_autotune:
-            tuned = env.autotune(auto_reset=args.auto_reset)     # untimed: picks workgroups-per-CU for this shape/device
-        actions = torch.randint(0, 4, (R, N), dtype=torch.int32, device=dev, generator=gen)
-        row_ptr = [actions[r].data_ptr() for r in range(R)]
+            # untimed: picks (workgroups per CU, chunks per workgroup) for this shape and device, on the very
+            # action tensor the timed steps read (cache-resident or not decides the ranking)
+            tuned = env.autotune(auto_reset=args.auto_reset, actions=actions)
 
         def run(k0, k, captured=False):
             for t in range(k0, k0 + k):
@@ -325,13 +330,14 @@ def main():
             "vs_baseline": None, "dtype": "f32" if foveal else "int32", "data": "synthetic",
             "config": {"workload": workload, "envs_per_gpu": N, "grid": G, "global_envs": world * N,
                        "parallelism": "independent env shards, no collective on the step path",
-                       "actions": "uniform{0..%d} int32[%d,N] ring, torch Philox seed 1+rank"
+                       "actions": "uniform{0..%d} int32[%d,N] on the device, row t %% rows at step t, torch Philox seed 1+rank"
                                   % ((FOVEAL_ACTIONS[args.workload] if foveal else 4) - 1, R),
                        "auto_reset": bool(args.auto_reset), "hip_graph": bool(args.graph),
                        "collective_backend": ("rccl" if backend == "nccl" else backend + " (REHEARSAL, ranks share a GPU)")
                        if dist is not None else None,
                        "launch_hint": None if foveal else int(env.params.launch_hint),
-                       "autotune_ms": {str(k): round(v, 5) for k, v in (tuned or {}).items()}},
+                       "autotune_ms": {("%dx%d" % k if isinstance(k, tuple) else str(k)): round(v, 5)
+                                       for k, v in (tuned or {}).items()}},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "kernel": ("lmaze::foveal_kernel<%s, FM_STEP>" % args.workload) if foveal else

@@ -173,6 +173,15 @@ __global__ __launch_bounds__(LMAZE_BLOCK) void foveal_kernel(const FovealArgs a)
     const int nb = (int)min((int64_t)EPB, a.n - blockbase);
     if (tid == 0) any_skip = 0;
     if (MODE == FM_STEP && AR) pass_epoch_on(a.epoch_in, a.epoch_out);
+    // large batches: the first 256 workgroups touch every 64-byte line of this step's action array at kernel
+    // start, one burst of reads, so that the per-workgroup loads later in the launch hit the memory-side cache
+    // instead of turning the saturated write stream around (lmaze_step.hip, step_shared_kernel)
+    int warmed = 0;
+    if (MODE == FM_STEP && a.nt && blockIdx.x < 256) {
+        const int64_t lines = (a.n * 4 + 63) / 64;
+        for (int64_t l = (int64_t)blockIdx.x * LMAZE_BLOCK + tid; l < lines; l += 256 * LMAZE_BLOCK)
+            warmed += a.action[min(l * 16, a.n - 1)];
+    }
     for (int i = tid; i < L * CELLS; i += LMAZE_BLOCK) lays[i] = a.layouts[i];
     __syncthreads();
     for (int i = tid; i < L * G; i += LMAZE_BLOCK) {
@@ -617,6 +626,7 @@ __global__ __launch_bounds__(LMAZE_BLOCK) void foveal_kernel(const FovealArgs a)
             reinterpret_cast<float4*>(loc)[q] = make_float4(v[0], v[1], v[2], v[3]);
         }
     }
+    if (warmed == 0x7fedcba9 && a.n < 0) a.b.done[0] = 1;   // never true: keeps the warming loads alive
 }
 
 // v6 safeFovealGoal (v6:505-523): one lane per env

@@ -126,14 +126,35 @@ __global__ __launch_bounds__(LMAZE_BLOCK) void step_shared_kernel(const StepArgs
     __shared__ int spawn_count_s;
 
     const int tid = threadIdx.x;
-    const int64_t blockbase = (int64_t)blockIdx.x * EPB;
-    const int nb = (int)min((int64_t)EPB, a.n - blockbase);  // envs in this workgroup
+    // A workgroup takes chunks of EPB envs grid-stride (chunk = blockIdx.x, + gridDim.x, ...): with one chunk
+    // each (gridDim.x = number of chunks) it is the plain one-chunk kernel; with several, the inputs of the
+    // NEXT chunk are loaded while the current one is being stored, so their latency -- several microseconds
+    // when they miss the caches and queue behind a saturated write stream -- is no longer exposed with only
+    // 3 workgroups resident per CU.  Consecutive workgroups still write consecutive chunks at any moment.
+    const int64_t nchunks = (a.n + EPB - 1) / EPB;
+    int64_t chunk = blockIdx.x;
+    int64_t blockbase = chunk * EPB;
+    int nb = (int)min((int64_t)EPB, a.n - blockbase);  // envs of the current chunk
     const bool masked = !DO_STEP && a.mask != nullptr;
     const bool autoreset = DO_STEP && a.auto_reset;
     if (autoreset) pass_epoch_on(a.epoch_in, a.epoch_out);
 
     EnvIn in{};
     if (tid < nb) in = load_env<VARIANT, DO_STEP>(a, blockbase + tid);
+
+    // Large batches (NT): the first 256 workgroups touch every 64-byte line of this step's action row at kernel
+    // start -- ONE burst of reads before the write stream saturates -- so that the chunk loads later in the
+    // launch find the row in the memory-side cache.  Actions are the one input that is new every step (state
+    // was written by the previous step and is still cached): read chunk by chunk from HBM they are 4 of 521
+    // bytes per env but cost 17-25 % of the rate, each small read turning a saturated write stream around
+    // (1M x 11x11, a fresh action row per step, 3 workgroups per CU x 2 chunks: 108 us without, 85-86 with;
+    // 86 us when the rows are cache-resident anyway).
+    int warmed = 0;
+    if (DO_STEP && NT && blockIdx.x < 256) {
+        const int64_t lines = (a.n * 4 + 63) / 64;
+        for (int64_t l = (int64_t)blockIdx.x * LMAZE_BLOCK + tid; l < lines; l += 256 * LMAZE_BLOCK)
+            warmed += a.action[min(l * 16, a.n - 1)];
+    }
 
     for (int i = tid; i < CELLS; i += LMAZE_BLOCK) lay[i] = a.layout[i];
     for (int i = tid; i < PAT; i += LMAZE_BLOCK) {
@@ -145,6 +166,16 @@ __global__ __launch_bounds__(LMAZE_BLOCK) void step_shared_kernel(const StepArgs
         if (tid == 0) spawn_count_s = cnt;
     }
     __syncthreads();
+
+  for (;;) {
+    const int64_t next = chunk + gridDim.x;
+    const bool has_next = next < nchunks;                         // uniform over the workgroup
+    EnvIn in_next{};
+    int nb_next = 0;
+    if (has_next) {                                               // issued now, consumed one chunk later
+        nb_next = (int)min((int64_t)EPB, a.n - next * EPB);
+        if (tid < nb_next) in_next = load_env<VARIANT, DO_STEP>(a, next * EPB + tid);
+    }
 
     if (tid < EPB) {  // one lane per env
         const int le = tid;
@@ -162,7 +193,7 @@ __global__ __launch_bounds__(LMAZE_BLOCK) void step_shared_kernel(const StepArgs
         if (V3) goalflat[le] = gf;
         if (masked) maskflag[le] = mf;
     }
-    if (a.obs == nullptr) return;
+    if (a.obs != nullptr) {
     __syncthreads();
 
     int32_t* obs = a.obs + (size_t)blockbase * CELLS;
@@ -234,6 +265,15 @@ __global__ __launch_bounds__(LMAZE_BLOCK) void step_shared_kernel(const StepArgs
         if (V3) v |= (goalflat[le] == off + c) ? LMAZE_OBS_GOAL : 0;
         if (!masked || maskflag[le]) obs[f] = v;
     }
+    }  // obs != nullptr
+    if (!has_next) break;
+    __syncthreads();   // the per-env cells in LDS are rewritten by the next chunk's phase 1
+    chunk = next;
+    blockbase = chunk * EPB;
+    nb = nb_next;
+    in = in_next;
+  }
+  if (warmed == 0x7fedcba9 && a.n < 0) a.done[0] = 1;   // never true: keeps the warming loads alive
 }
 
 // ------------------------------------------------------------------------------------
@@ -534,11 +574,21 @@ static hipError_t launch_shared(const StepArgs& a, hipStream_t s) {
         const size_t want = lds_for_workgroups_per_cu(per_cu);
         if (want > lds) lds = want;
     }
+    // chunks per workgroup (hint bits 4-7, 0 = default): the inputs of chunk k+1 are loaded while chunk k is
+    // stored, and the per-workgroup LDS set-up is shared.  Measured at 1M x 11x11 with a fresh action row from a
+    // [300,N] tensor every step, us per step, (workgroups per CU, chunks), two boxes:
+    //   (3,1) 93 / -    (3,2) 86 / 85    (4,2) 85 / 97    (5,2) 81 / 100    (8,1) 96 / -    persistent grids 98-127
+    // (before the action row was warmed at kernel start: (3,1) 113-115, (3,2) 108, (4,2) 94, (5,2) 87-91, (8,1) 91.)
+    // The optimum is narrow and moves from device to device; (3,2) is the one that held on both, so it is
+    // the default, and LmazeVecEnv.autotune() times the candidates on the caller's own action tensor.
+    int m = (a.launch_hint >> 4) & 15;
+    if (m == 0) m = nt ? 2 : 1;
+    const int64_t grid = (blocks + m - 1) / m;
     if (nt)
-        hipLaunchKernelGGL((step_shared_kernel<GT, VARIANT, DO_STEP, EPB, true>), dim3((unsigned)blocks),
+        hipLaunchKernelGGL((step_shared_kernel<GT, VARIANT, DO_STEP, EPB, true>), dim3((unsigned)grid),
                            dim3(LMAZE_BLOCK), lds, s, a);
     else
-        hipLaunchKernelGGL((step_shared_kernel<GT, VARIANT, DO_STEP, EPB, false>), dim3((unsigned)blocks),
+        hipLaunchKernelGGL((step_shared_kernel<GT, VARIANT, DO_STEP, EPB, false>), dim3((unsigned)grid),
                            dim3(LMAZE_BLOCK), lds, s, a);
     return hipGetLastError();
 }

@@ -235,37 +235,61 @@ class LmazeVecEnv(object):
                                    self._p_reward, self._p_done, self._p_gc, obs_ptr, N, st)
         _abi.check("lmaze_step_" + self.variant, rc)
 
-    def autotune(self, auto_reset=False, steps=8, candidates=(8, 4, 3, 2), warm=150):
-        """Pick the launch policy (LmazeParams.launch_hint = workgroups per CU) by timing real
-        steps with HIP events; the state is snapshotted and restored, so results are unaffected.
-        The best cap is narrow and shifts with (G, N, auto_reset) and between devices (see
-        lmaze_step.hip launch_shared), which is why it is measured rather than fixed.  `warm` untimed
-        launches come first: a cold device (the first ~100 launches of a process) ranks the candidates
-        differently from the steady state -- 4 per CU looks best cold and is 20 % behind 3 per CU once
-        warm (tools/autotune_study.py) -- and the steady state is what a rollout runs in.
-        Returns {candidate: ms per step}.  Only the shared-layout kernel has this knob."""
+    # launch policies autotune() tries: (workgroups per CU, chunks per workgroup) -> LmazeParams.launch_hint
+    CANDIDATES = ((3, 1), (3, 2), (4, 2), (5, 2), (5, 3), (6, 3), (7, 2), (8, 1), (8, 3))
+
+    @staticmethod
+    def launch_hint_of(per_cu, chunks=1):
+        """LmazeParams.launch_hint for `per_cu` workgroups per CU and `chunks` chunks per workgroup."""
+        return (int(per_cu) & 15) | ((int(chunks) & 15) << 4)
+
+    def autotune(self, auto_reset=False, actions=None, steps=16, candidates=None, warm=150):
+        """Pick the launch policy (LmazeParams.launch_hint: workgroups per CU, chunks per workgroup) by
+        timing real steps with HIP events; the state is snapshotted and restored, so results are unaffected.
+        The optimum is narrow and depends on shape, device and -- most of all -- on WHERE THE INPUTS COME
+        FROM: the policy that wins when actions and state sit in the Infinity Cache (3 workgroups per CU)
+        loses a third of its rate when the actions are a fresh row from HBM every step (lmaze_step.hip
+        launch_shared).  So pass the action tensor the rollout will use (`actions`: int32[T,N] on the
+        device; the rows are cycled exactly as rollout() would); without one, a private ring of rows larger
+        than the cache is generated, the conservative assumption.  `warm` untimed launches come first: a cold
+        device (the first ~100 launches of a process) ranks the candidates differently from the steady state.
+        Returns {(per_cu, chunks): ms per step}.  Only the shared-layout kernel has these knobs."""
         obs_bytes = self.num_envs * self.grid * self.grid * 4
         if self.layout_mode != _abi.LAYOUT_SHARED or obs_bytes <= (192 << 20):
-            return {}       # the cap only pays in the streaming (non-temporal store) regime
+            return {}       # the knobs only pay in the streaming (non-temporal store) regime
+        cands = [tuple(c) if isinstance(c, (tuple, list)) else (int(c), 1) for c in (candidates or self.CANDIDATES)]
+        N = self.num_envs
+        if actions is None:
+            rows = max(2, min(512, (320 << 20) // (4 * N) + 1))          # > 256 MiB of action rows
+            actions = torch.randint(0, 4, (rows, N), dtype=torch.int32, device=self.device)
+        elif not (isinstance(actions, torch.Tensor) and actions.dtype == torch.int32 and actions.dim() == 2
+                  and actions.shape[1] == N and actions.device == self.device and actions.is_contiguous()):
+            raise ValueError("autotune(actions=...) wants a contiguous int32[T,N] tensor on %s" % (self.device,))
+        base, stride, R = actions.data_ptr(), N * 4, int(actions.shape[0])
         snap, epoch = self._state.clone(), self._epoch
-        a = torch.randint(0, 4, (self.num_envs,), dtype=torch.int32, device=self.device)
-        timings = {}
+        timings, t = {}, 0
         with self._guard():
             for _ in range(int(warm)):
-                self._launch_step(a.data_ptr(), self._p_obs, auto_reset)
-            for c in candidates:
-                self.params.launch_hint = int(c)
-                self._launch_step(a.data_ptr(), self._p_obs, auto_reset)      # first launch of a new shape
-                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                e0.record()
-                for _ in range(steps):
-                    self._launch_step(a.data_ptr(), self._p_obs, auto_reset)
-                e1.record()
-                e1.synchronize()
-                timings[int(c)] = e0.elapsed_time(e1) / steps
+                self._launch_step(base + (t % R) * stride, self._p_obs, auto_reset)
+                t += 1
+            for _round in range(2):          # two interleaved passes, the minimum of the two counts
+                for c in cands:
+                    self.params.launch_hint = self.launch_hint_of(*c)
+                    self._launch_step(base + (t % R) * stride, self._p_obs, auto_reset)   # first launch of a new shape
+                    t += 1
+                    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    e0.record()
+                    for _ in range(steps):
+                        self._launch_step(base + (t % R) * stride, self._p_obs, auto_reset)
+                        t += 1
+                    e1.record()
+                    e1.synchronize()
+                    ms = e0.elapsed_time(e1) / steps
+                    timings[c] = min(ms, timings.get(c, ms))
             self._state.copy_(snap)
             self._epoch = epoch
-        self.params.launch_hint = min(timings, key=timings.get)
+        best = min(timings, key=timings.get)
+        self.params.launch_hint = self.launch_hint_of(*best)
         self.observe()
         return timings
 

@@ -74,8 +74,10 @@ typedef struct LmazeParams {
     float reward_move;   /* positiveNominal  -0.01  (v0:22)                                  */
     float reward_goal;   /* positiveFull    100.0   (v0:23)                                  */
     int32_t launch_hint; /* 0 = library default launch policy; else bits 0-3 = workgroups per
-                            CU, 1..8 (performance only, never results; lmaze_step.hip
-                            launch_shared; other bits must be 0)                             */
+                            CU (1..8, 0 = default), bits 4-7 = chunks of envs a workgroup
+                            takes one after the other, loading the next chunk's inputs while
+                            it stores the current one (1..15, 0 = default).  Performance only,
+                            never results (lmaze_step.hip launch_shared); other bits 0.      */
 } LmazeParams;
 
 int lmaze_abi_version(void);

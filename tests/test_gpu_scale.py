@@ -162,10 +162,13 @@ def test_autotune_keeps_results_and_state():
     ref = PKG.LmazeVecEnv(N, variant="v0", layout=lay, seed=6)
     before = env._state.clone()
     t = env.autotune()
-    assert set(t) == {8, 4, 3, 2} and env.params.launch_hint in t
+    assert set(t) == set(env.CANDIDATES) and env.params.launch_hint in [env.launch_hint_of(*c) for c in t]
     assert (env._state == before).all()
     acts = torch.randint(0, 4, (4, N), dtype=torch.int32, device="cuda")
-    for hint in (0, 2, 3, 5, 8):
+    t2 = env.autotune(actions=acts, candidates=((3, 1), (8, 2)), steps=4, warm=8)
+    assert set(t2) == {(3, 1), (8, 2)} and (env._state == before).all()
+    # workgroups per CU in bits 0-3, chunks per workgroup in bits 4-7: every combination, same results
+    for hint in (0, 2, 3, 5, 8, 0x13, 0x23, 0x48, 0xF7, 0x30):
         env.params.launch_hint = hint
         env._state.copy_(before)
         ref._state.copy_(before)
