@@ -167,6 +167,23 @@ __device__ __forceinline__ uint4 philox4x32_10(uint4 c, uint2 k) {
 }
 
 // the reset draw of one env: counter = (global env index, epoch), key = seed
+// Touch every 64-byte line of [p, p + bytes) once, the work spread over the first `blocks` workgroups of the
+// launch (one dword load per line; the sum only keeps the loads alive).  Used at kernel start to pull the
+// per-env inputs of a whole step into the memory-side cache in ONE burst of reads: fetched chunk by chunk in
+// the middle of the launch, each small read turns the saturated write stream around (lmaze_step.hip).
+__device__ __forceinline__ int warm_lines(const void* p, int64_t bytes, int blocks) {
+    int acc = 0;
+    if (p == nullptr || (int)blockIdx.x >= blocks) return 0;
+    const uintptr_t lo = reinterpret_cast<uintptr_t>(p) & ~(uintptr_t)3;          // dword loads: align down
+    const int64_t dwords = (int64_t)((reinterpret_cast<uintptr_t>(p) + (uintptr_t)bytes - lo) / 4);
+    if (dwords < 1) return 0;
+    const int64_t lines = (dwords + 15) / 16;
+    const int* q = reinterpret_cast<const int*>(lo);
+    for (int64_t l = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; l < lines; l += (int64_t)blocks * blockDim.x)
+        acc += q[min(l * 16, dwords - 1)];
+    return acc;
+}
+
 // epoch of this launch: the host's count plus the device-resident one, when the caller keeps one
 __device__ __forceinline__ uint64_t launch_epoch(uint64_t epoch, const uint64_t* epoch_in) {
     return epoch_in ? epoch + *epoch_in : epoch;

@@ -243,7 +243,7 @@ class LmazeVecEnv(object):
         """LmazeParams.launch_hint for `per_cu` workgroups per CU and `chunks` chunks per workgroup."""
         return (int(per_cu) & 15) | ((int(chunks) & 15) << 4)
 
-    def autotune(self, auto_reset=False, actions=None, steps=16, candidates=None, warm=150):
+    def autotune(self, auto_reset=False, actions=None, steps=16, candidates=None, warm=150, between=None):
         """Pick the launch policy (LmazeParams.launch_hint: workgroups per CU, chunks per workgroup) by
         timing real steps with HIP events; the state is snapshotted and restored, so results are unaffected.
         The optimum is narrow and depends on shape, device and -- most of all -- on WHERE THE INPUTS COME
@@ -251,8 +251,13 @@ class LmazeVecEnv(object):
         loses a third of its rate when the actions are a fresh row from HBM every step (lmaze_step.hip
         launch_shared).  So pass the action tensor the rollout will use (`actions`: int32[T,N] on the
         device; the rows are cycled exactly as rollout() would); without one, a private ring of rows larger
-        than the cache is generated, the conservative assumption.  `warm` untimed launches come first: a cold
-        device (the first ~100 launches of a process) ranks the candidates differently from the steady state.
+        than the cache is generated, the conservative assumption.  `between`: a callable that enqueues, on the
+        current stream, whatever runs between two steps in the real loop (the policy's forward pass): back to
+        back, consecutive step launches overlap head to tail and find their state in the cache, and 3
+        workgroups per CU win; with half a gigabyte of other traffic in between, that policy took 115 us per
+        step instead of 86 and 8 per CU took 93 (tools/evict_study.py) -- then each step is timed on its
+        own with an event pair and the median counts.  `warm` untimed launches come first: a cold device
+        (the first ~100 launches of a process) ranks the candidates differently from the steady state.
         Returns {(per_cu, chunks): ms per step}.  Only the shared-layout kernel has these knobs."""
         obs_bytes = self.num_envs * self.grid * self.grid * 4
         if self.layout_mode != _abi.LAYOUT_SHARED or obs_bytes <= (192 << 20):
@@ -277,14 +282,28 @@ class LmazeVecEnv(object):
                     self.params.launch_hint = self.launch_hint_of(*c)
                     self._launch_step(base + (t % R) * stride, self._p_obs, auto_reset)   # first launch of a new shape
                     t += 1
-                    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                    e0.record()
-                    for _ in range(steps):
-                        self._launch_step(base + (t % R) * stride, self._p_obs, auto_reset)
-                        t += 1
-                    e1.record()
-                    e1.synchronize()
-                    ms = e0.elapsed_time(e1) / steps
+                    if between is None:
+                        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                        e0.record()
+                        for _ in range(steps):
+                            self._launch_step(base + (t % R) * stride, self._p_obs, auto_reset)
+                            t += 1
+                        e1.record()
+                        e1.synchronize()
+                        ms = e0.elapsed_time(e1) / steps
+                    else:
+                        pairs = []
+                        for _ in range(steps):
+                            between()
+                            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                            e0.record()
+                            self._launch_step(base + (t % R) * stride, self._p_obs, auto_reset)
+                            e1.record()
+                            t += 1
+                            pairs.append((e0, e1))
+                        pairs[-1][1].synchronize()
+                        d = sorted(x.elapsed_time(y) for x, y in pairs)
+                        ms = d[len(d) // 2]
                     timings[c] = min(ms, timings.get(c, ms))
             self._state.copy_(snap)
             self._epoch = epoch

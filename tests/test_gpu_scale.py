@@ -167,6 +167,9 @@ def test_autotune_keeps_results_and_state():
     acts = torch.randint(0, 4, (4, N), dtype=torch.int32, device="cuda")
     t2 = env.autotune(actions=acts, candidates=((3, 1), (8, 2)), steps=4, warm=8)
     assert set(t2) == {(3, 1), (8, 2)} and (env._state == before).all()
+    scratch = torch.empty(32 << 20, dtype=torch.int32, device="cuda")
+    t3 = env.autotune(actions=acts, candidates=((3, 2), (8, 1)), steps=4, warm=8, between=lambda: scratch.add_(1))
+    assert set(t3) == {(3, 2), (8, 1)} and (env._state == before).all() and all(v > 0 for v in t3.values())
     # workgroups per CU in bits 0-3, chunks per workgroup in bits 4-7: every combination, same results
     for hint in (0, 2, 3, 5, 8, 0x13, 0x23, 0x48, 0xF7, 0x30):
         env.params.launch_hint = hint
