@@ -24,12 +24,15 @@ nbytes = src.numel() * 4
 
 
 WRITES = os.environ.get("INTERLOPER", "read") == "copy"
+SPIN = os.environ.get("INTERLOPER", "read") == "spin"      # no memory traffic at all: only separates the launches
 
 
 def interloper():
     """read: 512 MB of clean lines pass through the caches.  copy: 256 MB read + 256 MB written -- the dirty half
     is written back to HBM while the next step runs, traffic this script then charges to the step."""
-    if WRITES:
+    if SPIN:
+        torch.cuda._sleep(200000)        # ~100 us of spinning on one wave
+    elif WRITES:
         abi.lib.lmaze_bandwidth_probe(src.data_ptr(), dst.data_ptr(), nbytes, st)
     else:
         src.sum(); dst.sum()
