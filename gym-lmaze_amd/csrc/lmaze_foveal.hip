@@ -177,10 +177,13 @@ __global__ __launch_bounds__(LMAZE_BLOCK) void foveal_kernel(const FovealArgs a)
     // start, one burst of reads, so that the per-workgroup loads later in the launch hit the memory-side cache
     // instead of turning the saturated write stream around (lmaze_step.hip, step_shared_kernel)
     int warmed = 0;
-    if (MODE == FM_STEP && a.nt && blockIdx.x < 256) {
-        const int64_t lines = (a.n * 4 + 63) / 64;
-        for (int64_t l = (int64_t)blockIdx.x * LMAZE_BLOCK + tid; l < lines; l += 256 * LMAZE_BLOCK)
-            warmed += a.action[min(l * 16, a.n - 1)];
+    if (MODE == FM_STEP && a.nt) {
+        warmed = warm_lines(a.action, a.n * 4, 256);
+        if (!V4) {   // v1, v2: the per-env state as well (v2 -3 %); v4's read stream is the visit maps, and there it costs 5-10 %
+            warmed += warm_lines(a.b.ball_xy, a.n * 8, 256) + warm_lines(a.b.step_count, a.n * 4, 256);
+            if (V1) warmed += warm_lines(a.b.fgoal_xy, a.n * 8, 256) + warm_lines(a.b.foveal_step_count, a.n * 4, 256);
+            else warmed += warm_lines(a.b.goal_xy, a.n * 8, 256) + warm_lines(a.b.layout_id, a.n * 4, 256);
+        }
     }
     for (int i = tid; i < L * CELLS; i += LMAZE_BLOCK) lays[i] = a.layouts[i];
     __syncthreads();
