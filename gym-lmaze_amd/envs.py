@@ -17,7 +17,6 @@ returned scalars.  Everything step() computes runs in the kernel.
 import random
 
 import numpy as np
-import torch
 
 from . import layouts as L
 from ._staging import HostStaging
