@@ -48,12 +48,17 @@ def timed(fn, reps):
 
 for _ in range(200):
     env.step_raw(acts[0].data_ptr())
+TOUCH = os.environ.get("TOUCH_INPUTS", "0") == "1"   # after the interloper, read state + action row back into the caches
+
+
 def step_events(k, with_interloper):
     """Mean duration of the step launches alone (an event pair around every one of them)."""
     pairs = []
     for t in range(k):
         if with_interloper:
             interloper()
+            if TOUCH:
+                env._state.sum(); acts[t % T].sum()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
         env.step_raw(acts[t % T].data_ptr())
