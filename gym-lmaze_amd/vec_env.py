@@ -54,10 +54,14 @@ class LmazeVecEnv(object):
     per_env_layouts   uint8[N,G,G] (numpy or torch): every env has its own maze
     env_base          global index of local env 0 when the batch is one shard of a larger
                       one (keys the reset draws; see include/lmaze.h lmaze_reset)
+    online_autotune   large shared-layout batches only (the streaming regime): time the launch policies on
+                      the caller's own first few hundred steps, in the caller's own loop, and keep the
+                      fastest (see OnlineTuner); autotune() or set_launch_policy() switch it off
     """
 
     def __init__(self, num_envs, variant="v0", layout=None, per_env_layouts=None, device=None,
-                 expansion=None, step_limit=None, rewards=None, seed=0, env_base=0, validate=True):
+                 expansion=None, step_limit=None, rewards=None, seed=0, env_base=0, validate=True,
+                 online_autotune=True):
         if variant not in VARIANTS:
             raise ValueError("unknown variant %r (have %s)" % (variant, sorted(VARIANTS)))
         spec = VARIANTS[variant]
@@ -74,6 +78,7 @@ class LmazeVecEnv(object):
         self.env_base = int(env_base)
         self._epoch = 0
         self._epoch_words = None        # device-resident epoch pair, allocated by the first captured rollout
+        self.tuned_policy = None        # (per_cu, chunks) once autotune() or the online tuner has chosen
         self._is_v3 = variant == "v3"
 
         N = self.num_envs
@@ -127,6 +132,8 @@ class LmazeVecEnv(object):
         self._pp = C.byref(self.params)
         self._cmask = (C.c_int32 * len(self.channel_mask))(*self.channel_mask)
         self._bind_pointers()
+        streaming = self.layout_mode == _abi.LAYOUT_SHARED and N * G * G * 4 > (192 << 20)
+        self._tuner = OnlineTuner(self.CANDIDATES) if (online_autotune and streaming) else None
 
         if not self._is_v3:
             # v0 looks the goal up once from the layout (lmaze_env.py:100-102): first 'X', row-major
@@ -209,7 +216,28 @@ class LmazeVecEnv(object):
         self._epoch_words[0:1].fill_(self._epoch)
         self._epoch += int(n_launches)
 
+    def set_launch_policy(self, per_cu, chunks=1):
+        """Fix the launch policy (workgroups per CU, chunks per workgroup) and stop any tuning."""
+        self.params.launch_hint = self.launch_hint_of(per_cu, chunks)
+        self._tuner = None
+
     def _launch_step(self, action_ptr, obs_ptr, auto_reset, epoch_slot=None):
+        tuner = self._tuner
+        if tuner is not None and obs_ptr is not None and not torch.cuda.is_current_stream_capturing():
+            cand = tuner.next_candidate()
+            self.params.launch_hint = self.launch_hint_of(*cand)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            self._launch_step_raw(action_ptr, obs_ptr, auto_reset, epoch_slot)
+            e1.record()
+            best = tuner.add(cand, e0, e1)
+            if best is not None:                     # every candidate has its samples: keep the fastest
+                self.params.launch_hint = self.launch_hint_of(*best)
+                self.tuned_policy, self._tuner = best, None
+            return
+        self._launch_step_raw(action_ptr, obs_ptr, auto_reset, epoch_slot)
+
+    def _launch_step_raw(self, action_ptr, obs_ptr, auto_reset, epoch_slot=None):
         lib, N, st = _abi.lib, self.num_envs, self._stream()
         if auto_reset:
             seed = self.seed & (2 ** 64 - 1)
@@ -272,6 +300,7 @@ class LmazeVecEnv(object):
             raise ValueError("autotune(actions=...) wants a contiguous int32[T,N] tensor on %s" % (self.device,))
         base, stride, R = actions.data_ptr(), N * 4, int(actions.shape[0])
         snap, epoch = self._state.clone(), self._epoch
+        self._tuner = None                   # an explicit autotune replaces the online one
         timings, t = {}, 0
         with self._guard():
             for _ in range(int(warm)):
@@ -309,6 +338,7 @@ class LmazeVecEnv(object):
             self._epoch = epoch
         best = min(timings, key=timings.get)
         self.params.launch_hint = self.launch_hint_of(*best)
+        self.tuned_policy = best
         self.observe()
         return timings
 
@@ -387,6 +417,8 @@ class LmazeVecEnv(object):
         each other (lmaze_step_*_autoreset, epoch_in_dev / epoch_out_dev), so every replay draws fresh
         placements, and exactly those the same steps launched eagerly would draw."""
         T = int(actions.shape[0])
+        if self._tuner is not None:             # still cycling through candidates: a graph bakes the default policy
+            self.params.launch_hint = 0
         if auto_reset:
             self._epoch_word_ptrs(0)            # allocate before capture
         side = torch.cuda.Stream(device=self.device)
@@ -439,6 +471,38 @@ class LmazeVecEnv(object):
         return dict(ball_xy=v(self.ball_xy, np.int32, (N, 2)), goal_xy=v(self.goal_xy, np.int32, (N, 2)),
                     step_count=v(self.step_count, np.int32, (N,)), reward=v(self.reward, np.float32, (N,)),
                     goal_count=v(self.goal_count, np.int32, (N,)), done=v(self._done_u8, np.uint8, (N,)))
+
+
+class OnlineTuner:
+    """Launch-policy selection on the caller's own steps (LmazeVecEnv, streaming regime).  The best (workgroups
+    per CU, chunks per workgroup) pair depends on the device and on what else runs between two steps -- with
+    the per-env state still cached, 3 per CU wins; after half a gigabyte of other traffic, 8 per CU does
+     -- so instead of guessing, the first launches of a run cycle through the candidates, each
+    timed on its own with an event pair (no synchronisation: finished pairs are collected as they complete),
+    and once every candidate has `samples` timings the lowest median is kept.  `warm` launches are ignored first
+    (a cold device ranks differently).  Results never depend on the policy, only the pace of those launches."""
+
+    def __init__(self, candidates, warm=100, samples=12):
+        self.candidates = [tuple(c) for c in candidates]
+        self.warm, self.samples = int(warm), int(samples)
+        self.timings = {c: [] for c in self.candidates}
+        self._pending, self._count = [], 0
+
+    def next_candidate(self):
+        return self.candidates[self._count % len(self.candidates)]
+
+    def add(self, cand, e0, e1):
+        """Register one timed launch; returns the winner once every candidate has enough samples."""
+        self._count += 1
+        if self._count > self.warm:
+            self._pending.append((cand, e0, e1))
+        while self._pending and self._pending[0][2].query():
+            c, a, b = self._pending.pop(0)
+            self.timings[c].append(a.elapsed_time(b))
+        if all(len(v) >= self.samples for v in self.timings.values()):
+            med = {c: sorted(v)[len(v) // 2] for c, v in self.timings.items()}
+            return min(med, key=med.get)
+        return None
 
 
 class RolloutGraph:

@@ -417,3 +417,31 @@ def test_four_million_per_env_32x32_tail_against_the_oracle():
                       st["done"], st["goal_count"], ref)
     for sl, st, lay_np, ref in mirrors:
         assert (_np(env.obs[sl]) == ref).all() and (_np(env.ball_xy[sl]) == st["ball_xy"]).all(), sl
+
+
+def test_online_tuner_picks_a_policy_without_changing_results():
+    """Large shared-layout batches time the launch policies on their own first steps: the run with the tuner
+    cycling through its candidates and the run with a fixed policy produce the same bits, and after enough
+    launches the tuner has chosen and stepped aside."""
+    N, G = 1 << 19, 11                     # 254 MB of obs: the streaming regime
+    lay = L.to_codes(L.open_room(G, (5, 5)))
+    tuned = PKG.LmazeVecEnv(N, variant="v0", layout=lay, seed=6)
+    fixed = PKG.LmazeVecEnv(N, variant="v0", layout=lay, seed=6, online_autotune=False)
+    small = PKG.LmazeVecEnv(4096, variant="v0", layout=lay, seed=6)
+    assert tuned._tuner is not None and fixed._tuner is None and small._tuner is None
+    acts = torch.randint(0, 4, (8, N), dtype=torch.int32, device="cuda")
+    need = tuned._tuner.warm + tuned._tuner.samples * len(tuned.CANDIDATES) + 64
+    for t in range(need):
+        tuned.step(acts[t % 8], auto_reset=True)
+        fixed.step(acts[t % 8], auto_reset=True)
+        if t % 97 == 0:
+            assert (tuned.obs == fixed.obs).all() and (tuned._state == fixed._state).all(), t
+    torch.cuda.synchronize()
+    for t in range(16):                    # the last pairs are collected on later calls
+        tuned.step(acts[t % 8], auto_reset=True)
+        fixed.step(acts[t % 8], auto_reset=True)
+    assert tuned._tuner is None and tuned.tuned_policy in tuned.CANDIDATES
+    assert tuned.params.launch_hint == tuned.launch_hint_of(*tuned.tuned_policy)
+    assert (tuned.obs == fixed.obs).all() and (tuned._state == fixed._state).all()
+    tuned.set_launch_policy(8, 1)
+    assert tuned.params.launch_hint == 0x18
