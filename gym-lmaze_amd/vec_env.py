@@ -264,7 +264,7 @@ class LmazeVecEnv(object):
         _abi.check("lmaze_step_" + self.variant, rc)
 
     # launch policies autotune() tries: (workgroups per CU, chunks per workgroup) -> LmazeParams.launch_hint
-    CANDIDATES = ((3, 1), (3, 2), (4, 2), (5, 2), (5, 3), (6, 2), (6, 3), (7, 2), (8, 1), (8, 2), (8, 3))
+    CANDIDATES = ((3, 1), (3, 2), (4, 1), (4, 2), (5, 2), (5, 3), (6, 2), (6, 3), (7, 2), (8, 1), (8, 2), (8, 3))
 
     @staticmethod
     def launch_hint_of(per_cu, chunks=1):
