@@ -139,6 +139,8 @@ def main():
     ap.add_argument("--grid", type=int, default=None)
     ap.add_argument("--per-env-layouts", action="store_true", help="own random maze per env")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-baseline-seconds", type=float, default=12.0,
+                    help="CPU work spent on the cpu_baseline sample (the C oracle on the host cores)")
     ap.add_argument("--auto-reset", action="store_true",
                     help="lmaze_step_v0_autoreset: done envs are re-placed inside the step kernel (rollouts > 1 episode)")
     ap.add_argument("--no-autotune", action="store_true",
@@ -346,7 +348,8 @@ def main():
                          "bytes_per_env_step": B, "kernel_ms_avg": kern_ms, "measured_ceiling": ceiling},
         }
         if not args.no_cpu_baseline and world == 1:      # rank 0 at N=1 only
-            out["cpu_baseline"] = cpu_baseline_foveal(args.workload) if foveal else cpu_baseline(G, layout)
+            out["cpu_baseline"] = (cpu_baseline_foveal(args.workload, args.cpu_baseline_seconds) if foveal
+                                   else cpu_baseline(G, layout, args.cpu_baseline_seconds))
         print(json.dumps(out))
     if dist is not None:
         dist.destroy_process_group()
