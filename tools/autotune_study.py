@@ -13,7 +13,7 @@ sys.path.insert(0, ROOT)
 pkg = importlib.import_module("gym-lmaze_amd")
 
 N, G = 1 << 20, 11
-env = pkg.LmazeVecEnv(N, variant="v0", layout=pkg.layouts.to_codes(pkg.layouts.open_room(G, (5, 5))))
+env = pkg.LmazeVecEnv(N, variant="v0", layout=pkg.layouts.to_codes(pkg.layouts.open_room(G, (5, 5))), online_autotune=False)
 a = torch.randint(0, 4, (N,), dtype=torch.int32, device="cuda")
 
 

@@ -26,7 +26,7 @@ def main():
     N = args.envs
     # warm the device first: the first ~100 launches of a process run 10-40 % slow (clocks still ramping) and
     # would be charged to whichever variant is measured first
-    w = pkg.LmazeVecEnv(N, variant="v0", layout=pkg.layouts.to_codes(pkg.layouts.open_room(11, (5, 5))))
+    w = pkg.LmazeVecEnv(N, variant="v0", layout=pkg.layouts.to_codes(pkg.layouts.open_room(11, (5, 5))), online_autotune=False)
     a0 = torch.randint(0, 4, (N,), dtype=torch.int32, device="cuda")
     for _ in range(400):
         w.step_raw(a0.data_ptr())

@@ -15,7 +15,7 @@ pkg = importlib.import_module("gym-lmaze_amd")
 abi = pkg._abi
 
 N, G, T = 1 << 20, 11, 300
-env = pkg.LmazeVecEnv(N, variant="v0", layout=pkg.layouts.to_codes(pkg.layouts.open_room(G, (5, 5))))
+env = pkg.LmazeVecEnv(N, variant="v0", layout=pkg.layouts.to_codes(pkg.layouts.open_room(G, (5, 5))), online_autotune=False)
 acts = torch.randint(0, 4, (T, N), dtype=torch.int32, device="cuda")
 src = torch.empty(64 << 20, dtype=torch.int32, device="cuda")     # 256 MB
 dst = torch.empty_like(src)

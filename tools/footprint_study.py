@@ -3,7 +3,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 pkg = importlib.import_module("gym-lmaze_amd")
 N, G, T = 1 << 20, 11, 300
 lay = pkg.layouts.to_codes(pkg.layouts.open_room(G, (5, 5)))
-envs = [pkg.LmazeVecEnv(N, variant="v0", layout=lay, seed=s) for s in range(4)]
+envs = [pkg.LmazeVecEnv(N, variant="v0", layout=lay, seed=s, online_autotune=False) for s in range(4)]
 acts = torch.randint(0, 4, (T, N), dtype=torch.int32, device="cuda")
 def timed(fn, reps):
     fn(30); torch.cuda.synchronize()
