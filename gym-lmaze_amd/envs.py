@@ -105,11 +105,13 @@ class _LmazeBase(Env):
         """N = 1: upload the action, step, render xE, and bring observation + scalars back with one sync.
         Returns (page-locked view of the (C,GE,GE) observation or None in compact mode, host scalars)."""
         core, stage = self._core, self._stage
-        core.step(stage.action(action))
-        if self.obs_mode == "expanded":
-            got = stage.fetch(obs=core.expanded()[0], state=core._state)
-        else:
-            got = stage.fetch(state=core._state)
+        expanded = self.obs_mode == "expanded"
+
+        def body(act_dev):
+            core.step(act_dev)
+            return {"obs": core.expanded()[0], "state": core._state} if expanded else {"state": core._state}
+
+        got = stage.step(("step", expanded), action, body)       # one hipGraph launch + one sync
         self._host = core.host_state(raw=got["state"].copy())
         return got.get("obs"), self._host
 

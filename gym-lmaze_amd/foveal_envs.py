@@ -58,13 +58,18 @@ class _FovealBase(Env):
         """N = 1: upload the action, step, render x7, and bring the observation(s) + scalars back with one
         sync.  Returns ({"obs": view, "loc": view (v5/v6)}, host scalars); views are page-locked mirrors."""
         core, stage = self._core, self._stage
-        core.step(stage.action(action))
-        want = {"state": core._state}
-        if self.obs_mode == "expanded":
-            want["obs"] = core.expanded()[0]
-            if local:
-                want["loc"] = core.expanded_local()[0]
-        got = stage.fetch(**want)
+        expanded = self.obs_mode == "expanded"
+
+        def body(act_dev):
+            core.step(act_dev)
+            want = {"state": core._state}
+            if expanded:
+                want["obs"] = core.expanded()[0]
+                if local:
+                    want["loc"] = core.expanded_local()[0]
+            return want
+
+        got = stage.step(("step", expanded, local), action, body)    # one hipGraph launch + one sync
         self._host = core.host_state(raw=got["state"].copy())
         return got, self._host
 
