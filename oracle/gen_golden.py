@@ -565,8 +565,20 @@ def gen_flags():
     save("v2_fixed_start_seed4", rollout_v24("v2", foveal_actions(73, 160), seed=4, random_ball=False))
 
 
+# ----------------------------------------------------------------------------------------
+# 1 000-step rollouts of every step() variant (">= 1 000 random actions incl. out-of-range ids")
+# ----------------------------------------------------------------------------------------
+def gen_long():
+    save("v3_g18_long_seed4", rollout_v3(mixed_actions(81, 1000), seed=4))
+    save("v2_long_seed5", rollout_v24("v2", foveal_actions(82, 1000), seed=5))
+    save("v4_long_seed6", rollout_v24("v4", foveal_actions(83, 1000), seed=6))
+    fg = np.random.RandomState(84).randint(0, 5, (200, 2))
+    save("v1_long_seed7", rollout_v1(mixed_actions(85, 1000, lo=-1, hi=5), fg, seed=7))
+    save("v0_g12_long_seed8", rollout_v0(None, mixed_actions(86, 1000), seed=8))
+
+
 GENERATORS = {"v0": gen_v0, "v3": gen_v3, "v1": gen_v1, "v2": gen_v2, "v4": gen_v4, "v5": gen_v5, "v6": gen_v6,
-              "flags": gen_flags}
+              "flags": gen_flags, "long": gen_long}
 
 if __name__ == "__main__":
     which = sys.argv[1:] or sorted(GENERATORS)
