@@ -14,7 +14,7 @@ from .compat import make, register, registered_ids  # noqa: F401
 from .envs import LmazeEnv, LmazeEnv_v3  # noqa: F401
 from .foveal_env import FOVEAL_VARIANTS, LmazeFovealVecEnv  # noqa: F401
 from .foveal_envs import LmazeEnv_v1, LmazeEnv_v2, LmazeEnv_v4, LmazeEnv_v5, LmazeEnv_v6  # noqa: F401
-from .sharding import max_over_ranks, shard_range, sum_over_ranks  # noqa: F401
+from .sharding import gather_over_ranks, max_over_ranks, shard_range, sum_over_ranks  # noqa: F401
 from .vec_env import VARIANTS, LmazeVecEnv  # noqa: F401
 
 __all__ = ["LmazeVecEnv", "LmazeFovealVecEnv", "FOVEAL_VARIANTS", "LmazeEnv", "LmazeEnv_v1", "LmazeEnv_v2", "LmazeEnv_v3", "LmazeEnv_v4", "LmazeEnv_v5", "LmazeEnv_v6", "VARIANTS", "layouts", "make", "register",

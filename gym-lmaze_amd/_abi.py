@@ -16,7 +16,7 @@ import torch  # noqa: F401
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("LMAZE_HIP_LIB") or os.path.join(HERE, "liblmaze_hip.so")   # override: another build of the same ABI
 
-ABI_VERSION = 2
+ABI_VERSION = 3
 VARIANT_V0, VARIANT_V3 = 0, 3
 VARIANT_V1, VARIANT_V2, VARIANT_V4, VARIANT_V5, VARIANT_V6 = 1, 2, 4, 5, 6
 FOVEA = 5
@@ -29,7 +29,7 @@ MAX_GRID, MAX_CHANNELS = 64, 8
 SYMBOLS = ("lmaze_abi_version", "lmaze_strerror", "lmaze_device_info", "lmaze_step_v0", "lmaze_step_v3",
            "lmaze_step_v0_autoreset", "lmaze_step_v3_autoreset", "lmaze_observe", "lmaze_reset",
            "lmaze_episode_stats", "lmaze_bandwidth_probe", "lmaze_render_expanded", "lmaze_foveal_step", "lmaze_foveal_step_autoreset", "lmaze_foveal_reset", "lmaze_v1_set_foveal_goal",
-           "lmaze_v5_planner_step", "lmaze_v6_safe_foveal_goal", "lmaze_expand_planes")
+           "lmaze_v5_planner_step", "lmaze_v5_hier_step", "lmaze_v6_safe_foveal_goal", "lmaze_expand_planes")
 
 
 class LmazeParams(C.Structure):
@@ -43,7 +43,7 @@ class LmazeFovealParams(C.Structure):
     """struct LmazeFovealParams of include/lmaze.h."""
     _fields_ = [("variant", C.c_int32), ("grid", C.c_int32), ("n_layouts", C.c_int32), ("step_limit", C.c_int32),
                 ("foveal_step_limit", C.c_int32), ("reward_wall", C.c_float), ("reward_move", C.c_float),
-                ("reward_goal", C.c_float)]
+                ("reward_goal", C.c_float), ("launch_hint", C.c_int32)]
 
 
 FOVEAL_BUFFER_FIELDS = ("ball_xy", "goal_xy", "fgoal_xy", "layout_id", "step_count", "foveal_step_count",
@@ -62,19 +62,29 @@ class LmazeError(RuntimeError):
         RuntimeError.__init__(self, "%s failed: %d (%s)" % (fn, code, strerror(code)))
 
 
+def _sources():
+    """csrc/*.hip, csrc/*.h and include/lmaze.h: what liblmaze_hip.so is built from."""
+    src = os.path.join(HERE, "csrc")
+    out = [os.path.join(src, f) for f in sorted(os.listdir(src)) if f.endswith((".hip", ".h"))] if os.path.isdir(src) else []
+    hdr = os.path.join(os.path.dirname(HERE), "include", "lmaze.h")
+    return out + ([hdr] if os.path.exists(hdr) else [])
+
+
 def _load():
     if not os.path.exists(LIB_PATH):
-        # a fresh checkout: build the library once (hipcc cross-compiles gfx950 without a GPU); this is
-        # still the only implementation -- if the build is impossible the import fails below
-        import subprocess
-        try:
-            subprocess.check_call(["make", "-C", os.path.join(HERE, "csrc"), "-s", "-j4"])
-        except Exception:
-            pass
-    if not os.path.exists(LIB_PATH):
+        # never built behind the caller's back: under torchrun every rank of a fresh checkout would race to
+        # compile and link the same files, and a silent build hides a toolchain problem
         raise ImportError(
             "gym-lmaze_amd: %s is missing. The HIP library is the only compute path (no CPU fallback); "
-            "build it with `make -C %s` (hipcc, --offload-arch=gfx950)." % (LIB_PATH, os.path.join(HERE, "csrc")))
+            "build it with `make -C %s` (hipcc, --offload-arch=gfx950) or `python -c 'import __graft_entry__ as g; "
+            "g.build()'`." % (LIB_PATH, os.path.join(HERE, "csrc")))
+    if "LMAZE_HIP_LIB" not in os.environ:
+        stale = [f for f in _sources() if os.path.getmtime(f) > os.path.getmtime(LIB_PATH)]
+        if stale:
+            import warnings
+            warnings.warn("gym-lmaze_amd: %s is older than %s -- rebuild with `make -C %s`"
+                          % (os.path.basename(LIB_PATH), ", ".join(os.path.basename(f) for f in stale),
+                             os.path.join(HERE, "csrc")), RuntimeWarning, stacklevel=3)
     lib = C.CDLL(LIB_PATH)
     vp, i32, i64, u64 = C.c_void_p, C.c_int32, C.c_int64, C.c_uint64
     P = C.POINTER(LmazeParams)
@@ -113,6 +123,8 @@ def _load():
     lib.lmaze_v1_set_foveal_goal.argtypes = [FP, vp, vp, vp, FB, i64, vp]
     lib.lmaze_v5_planner_step.restype = C.c_int
     lib.lmaze_v5_planner_step.argtypes = [FP, vp, vp, vp, FB, i64, vp]
+    lib.lmaze_v5_hier_step.restype = C.c_int
+    lib.lmaze_v5_hier_step.argtypes = [FP, vp, vp, vp, FB, i64, u64, u64, i64, vp, vp, vp]
     lib.lmaze_v6_safe_foveal_goal.restype = C.c_int
     lib.lmaze_v6_safe_foveal_goal.argtypes = [FP, vp, u64, u64, i64, FB, vp, i64, vp]
     lib.lmaze_expand_planes.restype = C.c_int

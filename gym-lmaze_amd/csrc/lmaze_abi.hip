@@ -12,7 +12,7 @@ static int check_params(const LmazeParams* p, int64_t n) {
     if (!p) return LMAZE_E_NULL;
     if (p->grid < 3 || p->grid > LMAZE_MAX_GRID) return LMAZE_E_GRID;
     if (p->layout_mode != LMAZE_LAYOUT_SHARED && p->layout_mode != LMAZE_LAYOUT_PER_ENV) return LMAZE_E_LAYOUT;
-    if (n < 0 || n > ((int64_t)1 << 40)) return LMAZE_E_COUNT;
+    if (n < 0 || n > LMAZE_MAX_ENVS) return LMAZE_E_COUNT;
     return 0;
 }
 
@@ -199,14 +199,14 @@ int lmaze_reset(const LmazeParams* params, const uint8_t* layout, const uint8_t*
 int lmaze_episode_stats(const uint8_t* done, const float* reward, const int32_t* step_count,
                         const int32_t* goal_count, float reward_goal, int64_t n, int64_t* out4, void* stream) {
     if (!done || !reward || !step_count || !out4) return LMAZE_E_NULL;
-    if (n < 0 || n > ((int64_t)1 << 40)) return LMAZE_E_COUNT;
+    if (n < 0 || n > LMAZE_MAX_ENVS) return LMAZE_E_COUNT;
     if (misaligned(out4, 8)) return LMAZE_E_ALIGN;
     return (int)launch_episode_stats(done, reward, step_count, goal_count, reward_goal, n, out4, (hipStream_t)stream);
 }
 
 int lmaze_bandwidth_probe(const void* src, void* dst, int64_t bytes, void* stream) {
     if (!dst) return LMAZE_E_NULL;
-    if (bytes < 0 || bytes > ((int64_t)1 << 40) || (bytes & 15)) return LMAZE_E_COUNT;
+    if (bytes < 0 || bytes > ((int64_t)1 << 36) || (bytes & 15)) return LMAZE_E_COUNT;
     if (misaligned(dst, 16) || (src && misaligned(src, 16))) return LMAZE_E_ALIGN;
     return (int)launch_probe(src, dst, bytes, (hipStream_t)stream);
 }
@@ -216,7 +216,7 @@ int lmaze_render_expanded(const int32_t* obs, int32_t grid, int32_t expansion, c
     if (!obs || !channel_mask_host || !out) return LMAZE_E_NULL;
     if (grid < 1 || grid > LMAZE_MAX_GRID) return LMAZE_E_GRID;
     if (expansion < 1 || expansion > 16 || channels < 1 || channels > LMAZE_MAX_CHANNELS) return LMAZE_E_EXPANSION;
-    if (n < 0 || n > ((int64_t)1 << 40)) return LMAZE_E_COUNT;
+    if (n < 0 || n > LMAZE_MAX_ENVS) return LMAZE_E_COUNT;
     if (misaligned(out, 16) || misaligned(obs, 4)) return LMAZE_E_ALIGN;
     ExpandArgs a;
     a.obs = obs;

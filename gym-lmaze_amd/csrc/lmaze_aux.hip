@@ -87,12 +87,14 @@ hipError_t launch_reset(int variant, const ResetArgs& a, int layout_mode, hipStr
     if (a.n == 0) return hipSuccess;
     const bool v3 = variant == LMAZE_VARIANT_V3;
     if (layout_mode == LMAZE_LAYOUT_SHARED) {
+        if (!grid_ok((a.n + LMAZE_BLOCK - 1) / LMAZE_BLOCK)) return hipErrorInvalidConfiguration;
         const unsigned blocks = (unsigned)((a.n + LMAZE_BLOCK - 1) / LMAZE_BLOCK);
         const size_t lds = ((size_t)a.grid * a.grid * 2 + 15) & ~(size_t)15;
         if (v3) hipLaunchKernelGGL(reset_shared_kernel<LMAZE_VARIANT_V3>, dim3(blocks), dim3(LMAZE_BLOCK), lds, s, a);
         else hipLaunchKernelGGL(reset_shared_kernel<LMAZE_VARIANT_V0>, dim3(blocks), dim3(LMAZE_BLOCK), lds, s, a);
     } else {
         const int epb = LMAZE_BLOCK / 64;
+        if (!grid_ok((a.n + epb - 1) / epb)) return hipErrorInvalidConfiguration;
         const unsigned blocks = (unsigned)((a.n + epb - 1) / epb);
         const bool wave = (a.grid == 16 && launch_reset_wave<16>(v3, a, blocks, s)) ||
                           (a.grid == 32 && launch_reset_wave<32>(v3, a, blocks, s)) ||
@@ -286,6 +288,7 @@ hipError_t launch_probe(const void* src, void* dst, int64_t bytes, hipStream_t s
     const int64_t n16 = bytes / 16;
     if (n16 == 0) return hipSuccess;
     const int64_t blocks = (n16 + LMAZE_BLOCK - 1) / LMAZE_BLOCK;
+    if (!grid_ok(blocks)) return hipErrorInvalidConfiguration;
     if (src)
         hipLaunchKernelGGL(probe_copy_kernel, dim3((unsigned)blocks), dim3(LMAZE_BLOCK), 0, s,
                            static_cast<const int4*>(src), static_cast<int4*>(dst), n16);
@@ -397,7 +400,7 @@ static hipError_t launch_expand_stream(const ExpandArgs& a, hipStream_t s) {
     if (b.chunk_floats < 1024) return launch_expand_generic(a, s);
     const int64_t chunks = (total + b.chunk_floats - 1) / b.chunk_floats;
     // out must start on a cache line for the stretches to be aligned
-    if (chunks > 0x7fffffff || ((uintptr_t)a.out & 63)) return launch_expand_generic(a, s);
+    if (!grid_ok(chunks) || ((uintptr_t)a.out & 63)) return launch_expand_generic(a, s);
     size_t lds = ((size_t)2 * GT * GT * 4 + LMAZE_MAX_CHANNELS * 4 + 15) & ~(size_t)15;
     const bool nt = total * 4 > ((int64_t)192 << 20);                // cannot stay in the 256 MiB Infinity Cache
     if (nt) {
@@ -415,7 +418,7 @@ static hipError_t launch_planes_stream(const ExpandArgs& a, hipStream_t s) {
     ExpandArgs b = a;
     b.chunk_floats = 8192;                                           // 32 KiB per workgroup
     const int64_t chunks = (total + b.chunk_floats - 1) / b.chunk_floats;
-    if (cells < 4 || chunks > 0x7fffffff || ((uintptr_t)a.out & 63)) return launch_expand_generic(a, s);
+    if (cells < 4 || !grid_ok(chunks) || ((uintptr_t)a.out & 63)) return launch_expand_generic(a, s);
     b.inv_l = (((uint64_t)1 << 32) + (uint64_t)L - 1) / (uint64_t)L;
     b.inv_cells = (((uint64_t)1 << 32) + (uint64_t)cells - 1) / (uint64_t)cells;
     size_t lds = ((size_t)(b.chunk_floats / L + 3) * cells * 4 + 15) & ~(size_t)15;

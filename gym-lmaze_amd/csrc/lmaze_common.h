@@ -73,6 +73,11 @@ inline bool bad_epoch_words(const uint64_t* in, const uint64_t* out) {
     return ((((uintptr_t)in) | ((uintptr_t)out)) & 7) != 0 || (in && in == out) || (!in && out);
 }
 
+// A launch of `blocks` workgroups of LMAZE_BLOCK threads is accepted by HIP only while blocks * LMAZE_BLOCK
+// stays below 2^32; every launcher checks its block count (computed in 64 bits) with this before narrowing it,
+// so an over-large env count is refused with hipErrorInvalidConfiguration instead of wrapping the grid.
+inline bool grid_ok(int64_t blocks) { return blocks >= 1 && blocks <= (int64_t)0xFFFFFF; }
+
 hipError_t launch_step(int variant, bool do_step, const StepArgs& a, int layout_mode, hipStream_t s);
 hipError_t launch_reset(int variant, const ResetArgs& a, int layout_mode, hipStream_t s);
 hipError_t launch_expand(const ExpandArgs& a, hipStream_t s);
@@ -131,28 +136,6 @@ __device__ __forceinline__ bool transition_rule(const StepArgs& a, uint8_t c, in
     return hit;
 }
 
-// One env's transition against `lay`, that env's layout (LDS), with the SoA loads/stores.
-// Out-of-range coordinates cannot occur with a 'W'-bordered layout (the reference would
-// raise IndexError or wrap); indices are clamped only so a bad input cannot fault the GPU.
-template <int VARIANT>
-__device__ __forceinline__ void transition(const StepArgs& a, const uint8_t* lay, int G, int64_t e,
-                                           int sc_in, float r_in, int& bx, int& by, int gx, int gy) {
-    const int act = a.action[e];
-    const int sc = sc_in + 1;  // v0:151, v3:225
-    int ox, oy;
-    decode_action(act, ox, oy);
-    const int tx = clampi(bx + ox, 0, G - 1), ty = clampi(by + oy, 0, G - 1);
-    const uint8_t c = lay[tx * G + ty];  // v0:172, v3:251
-    float r;
-    bool dn;
-    if (transition_rule<VARIANT>(a, c, ox, oy, tx, ty, sc, r_in, gx, gy, bx, by, r, dn) && a.goal_count)
-        a.goal_count[e] += 1;
-    a.ball[e] = make_int2(bx, by);
-    a.step_count[e] = sc;
-    a.reward[e] = r;
-    a.done[e] = dn ? 1 : 0;
-}
-
 // Philox4x32-10 (Salmon, Moraes, Dror, Shaw: "Parallel random numbers: as easy as 1, 2, 3", SC'11)
 __device__ __forceinline__ uint4 philox4x32_10(uint4 c, uint2 k) {
 #pragma unroll
@@ -166,7 +149,6 @@ __device__ __forceinline__ uint4 philox4x32_10(uint4 c, uint2 k) {
     return c;
 }
 
-// the reset draw of one env: counter = (global env index, epoch), key = seed
 // Touch every 64-byte line of [p, p + bytes) once, the work spread over the first `blocks` workgroups of the
 // launch (one dword load per line; the sum only keeps the loads alive).  Used at kernel start to pull the
 // per-env inputs of a whole step into the memory-side cache in ONE burst of reads: fetched chunk by chunk in
@@ -194,6 +176,7 @@ __device__ __forceinline__ void pass_epoch_on(const uint64_t* epoch_in, uint64_t
     if (epoch_in && epoch_out && blockIdx.x == 0 && threadIdx.x == 0) *epoch_out = *epoch_in + 1;
 }
 
+// the reset draw of one env: counter = (global env index, epoch), key = seed
 __device__ __forceinline__ uint4 env_draw(uint64_t seed, uint64_t epoch, int64_t env_global) {
     const uint64_t e = (uint64_t)env_global;
     return philox4x32_10(make_uint4((uint32_t)e, (uint32_t)(e >> 32), (uint32_t)epoch, (uint32_t)(epoch >> 32)),

@@ -26,6 +26,7 @@ struct FovealArgs {
     LmazeFovealBuffers b;
     const uint8_t* layouts;
     const int32_t* action;  // step: action ids; setgoal: ij[N,2]
+    const int32_t* goal2;   // v5 two-level step: planner goals (plannerStep of the envs that enter with localDone / done)
     const uint8_t* mask;
     int64_t n;
     int32_t place;
@@ -139,6 +140,20 @@ __device__ __forceinline__ uint32_t onehot_bits(int tx, int ty, int cx, int cy) 
     return (i >= 0 && i < FOV && j >= 0 && j < FOV) ? (1u << (FOV * i + j)) : 0u;
 }
 
+// OR the 25-bit plane m into a bit string at bit offset off (LDS atomics: neighbouring envs share words)
+__device__ __forceinline__ void put_bits(uint32_t* bits, int off, uint32_t m) {
+    const int w = off >> 5, sh = off & 31;
+    atomicOr(&bits[w], m << sh);
+    if (sh > 32 - W25) atomicOr(&bits[w + 1], m >> (32 - sh));
+}
+
+// four consecutive floats (0.0f / 1.0f) from nibble q of a bit string
+__device__ __forceinline__ void nibble_floats(const uint32_t* bits, int q, float (&v)[4]) {
+    const uint32_t nib = bits[q >> 3] >> ((q & 7) << 2);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) v[k] = __uint_as_float((0u - ((nib >> k) & 1u)) & 0x3f800000u);
+}
+
 // GT = grid side known at compile time (14 and 18, the reference's sizes; 0: read it from the params):
 // the visit-map stream divides by G for every cell, which is only cheap with a constant
 // AR = fused auto-reset compiled in (a separate instantiation: the extra state it threads through the
@@ -166,12 +181,18 @@ __global__ __launch_bounds__(LMAZE_BLOCK) void foveal_kernel(const FovealArgs a)
     uint64_t* rowwall = rowball + L * G;                                   // [G] v1: 'W'
     uint64_t* rowx = rowwall + G;                                          // [G] v1: 'X'
     uint8_t* lays = reinterpret_cast<uint8_t*>(rowx + G);                  // [L*CELLS]
+    // the 0/1 planes of the workgroup's observations as ONE bit string, bit f = float f of the workgroup's
+    // contiguous output range (v1, v2: obs; v5/v6: obs_local): a 16-byte store is then one nibble of it
+    uint32_t* obits = reinterpret_cast<uint32_t*>(lays + ((L * CELLS + 15) & ~15));   // [BITW]
+    constexpr int BITW = (EPB * (V5 ? 4 * W25 : PERENV) + 31) / 32 + 1;
     __shared__ int any_skip;
 
     const int tid = threadIdx.x;
     const int64_t blockbase = (int64_t)blockIdx.x * EPB;
     const int nb = (int)min((int64_t)EPB, a.n - blockbase);
     if (tid == 0) any_skip = 0;
+    if (!V4 || V5)
+        for (int i = tid; i < BITW; i += LMAZE_BLOCK) obits[i] = 0u;
     if (MODE == FM_STEP && AR) pass_epoch_on(a.epoch_in, a.epoch_out);
     // large batches: the first 256 workgroups touch every 64-byte line of this step's action array at kernel
     // start, one burst of reads, so that the per-workgroup loads later in the launch hit the memory-side cache
@@ -288,14 +309,53 @@ __global__ __launch_bounds__(LMAZE_BLOCK) void foveal_kernel(const FovealArgs a)
             int b1x = a.b.ball1_xy[2 * e], b1y = a.b.ball1_xy[2 * e + 1];
             int lx = a.b.last_xy[2 * e], ly = a.b.last_xy[2 * e + 1];
             if (MODE == FM_STEP) {                                     // v5:187-292
-                const uint8_t* lay = lays + lid * CELLS;
                 const int act = a.action[e];
-                const int fgx = a.b.fgoal_xy[2 * e], fgy = a.b.fgoal_xy[2 * e + 1];
-                const int fsc = a.b.foveal_step_count[e];
+                int fgx = a.b.fgoal_xy[2 * e], fgy = a.b.fgoal_xy[2 * e + 1];
+                int fsc = a.b.foveal_step_count[e];
+                int sc_in = a.b.step_count[e];
                 bool ld = a.b.foveal_done[e] != 0, gd = a.b.done[e] != 0;   // both persist across step() calls
+                if (AR) {
+                    // the two-level loop around step() (lmaze_v5_hier_step): reset() for an env that enters with
+                    // globalDone, plannerStep(goal) for one that enters with localDone or was just reset
+                    const bool plan = ld || gd;
+                    bool planned = false;
+                    if (gd) {                                          // reset(): v5:104-150, as FM_RESET below
+                        const uint4 d = env_draw(a.seed, launch_epoch(a.epoch, a.epoch_in), a.env_base + e);
+                        lid = (int)__umulhi(d.z, (uint32_t)L);         // v5:105 setGrid first
+                        int goal_cell, ball_cell;
+                        place_goal_ball(rowgoal + lid * G, rowball + lid * G, G, d, goal_cell, ball_cell);
+                        if (goal_cell >= 0) { gx = goal_cell / G; gy = goal_cell % G; }
+                        if (ball_cell >= 0) { bx = ball_cell / G; by = ball_cell % G; }
+                        a.b.layout_id[e] = lid;
+                        a.b.goal_xy[2 * e] = gx; a.b.goal_xy[2 * e + 1] = gy;
+                        fsc = 0; sc_in = 0; gd = false; ld = false;    // v5:109-112
+                        fg = 12;                                       // v5:127-128
+                        f0x = f1x = b1x = lx = fgx = bx; f0y = f1y = b1y = ly = fgy = by;   // v5:136-143
+                        fresh = true;
+                    }
+                    if (plan) {                                        // plannerStep(goal): v5:158-182, as FM_PLANNER below
+                        const int g = a.goal2[e];
+                        if (g >= 0 && g < W25) {
+                            fg = g;
+                            sc_in = 0;                                 // v5:160
+                            ld = false;                                // v5:162
+                            fgx = bx + g / FOV - 2; fgy = by + g % FOV - 2;   // v5:172-173
+                            if (fsc > 0) { f1x = f0x; f1y = f0y; }     // v5:175-177
+                            fsc += 1;                                  // v5:179
+                            planned = true;
+                        }
+                    }
+                    if (fresh || planned) {
+                        a.b.foveal_goal[e] = fg;
+                        a.b.fgoal_xy[2 * e] = fgx; a.b.fgoal_xy[2 * e + 1] = fgy;
+                        a.b.fovea_xy[4 * e + 2] = f1x; a.b.fovea_xy[4 * e + 3] = f1y;
+                        a.b.foveal_step_count[e] = fsc;
+                    }
+                }
+                const uint8_t* lay = lays + lid * CELLS;
                 b1x = bx; b1y = by;                                    // v5:193-194
                 float lr = -0.0f, gr;                                  // v5:196
-                const int sc = a.b.step_count[e] + 1;                  // v5:197
+                const int sc = sc_in + 1;                              // v5:197
                 const int dx = (act == 0) - (act == 1), dy = (act == 2) - (act == 3);   // v5:205-217
                 const int nx = bx + dx, ny = by + dy;
                 const bool nin = nx >= 0 && ny >= 0 && nx < G && ny < G;
@@ -448,7 +508,8 @@ __global__ __launch_bounds__(LMAZE_BLOCK) void foveal_kernel(const FovealArgs a)
         }
         r.cx = (int16_t)bx; r.cy = (int16_t)by;
         // the observation as 25-bit planes (the float visit planes are sampled in phase 3)
-        uint32_t* m = masks + le * 8;
+        uint32_t mreg[8];
+        uint32_t* m = V4 ? masks + le * 8 : mreg;     // v1, v2: straight into the workgroup's bit string below
         if (V1) {
             m[0] = 1u << 12;                                                               // ball, v1:216
             m[1] = window_bits(rowwall, G, r.cx, r.cy);
@@ -464,14 +525,20 @@ __global__ __launch_bounds__(LMAZE_BLOCK) void foveal_kernel(const FovealArgs a)
             m[PER + 1] = window_bits(rows, G, r.px, r.py);
             m[PER + 2] = onehot_bits(r.gx, r.gy, r.px, r.py);
             if (V5) {                                                                      // v5:356-380
-                uint32_t* lm = lmasks + le * 4;
+                uint32_t lm[4];
                 lm[0] = m[0];
                 const int i0 = wrap5(r.b0x - r.f1x + 2), j0 = wrap5(r.b0y - r.f1y + 2);
                 const int i1 = wrap5(r.b1x - r.f1x + 2), j1 = wrap5(r.b1y - r.f1y + 2);
                 lm[1] = (i0 >= 0 && j0 >= 0) ? (1u << (FOV * i0 + j0)) : 0u;
                 lm[2] = (i1 >= 0 && j1 >= 0) ? (1u << (FOV * i1 + j1)) : 0u;
                 lm[3] = m[PER];
+                if (MODE != FM_RESET && !r.skip)
+                    for (int ch = 0; ch < 4; ++ch) put_bits(obits, le * (4 * W25) + ch * W25, lm[ch]);
             }
+        }
+        if (!V4 && !r.skip) {
+#pragma unroll
+            for (int ch = 0; ch < C; ++ch) put_bits(obits, le * PERENV + ch * W25, m[ch]);
         }
         cen[le * 4 + 0] = r.cx; cen[le * 4 + 1] = r.cy; cen[le * 4 + 2] = r.px; cen[le * 4 + 3] = r.py;
         flags[le] = (r.skip ? 1 : 0) | (r.upd ? 2 : 0) | (fresh ? 4 : 0) | (nostep ? 8 : 0);
@@ -510,22 +577,24 @@ __global__ __launch_bounds__(LMAZE_BLOCK) void foveal_kernel(const FovealArgs a)
                 const int c0 = f0 - le * CELLS;
                 const int fl = flags[le];
                 const bool skip = fl & 1, upd = fl & 2;
-                if (skip || (V5 && MODE == FM_STEP && !upd)) continue;      // map unchanged: gathered below
-                const int cx = cen[le * 4], cy = cen[le * 4 + 1];
                 const bool fresh = MODE == FM_STEP && AR && (fl & 4), nostep = MODE == FM_STEP && AR && (fl & 8);
+                if (skip || (V5 && MODE == FM_STEP && !upd && !fresh)) continue;   // map unchanged: gathered below
+                const int cx = cen[le * 4], cy = cen[le * 4 + 1];
                 float4 v = make_float4(0.f, 0.f, 0.f, 0.f);                 // reset: v4:112 / v5:130
                 // STEP loads unconditionally (a load that waits on the per-env flag does not pipeline: the fused
                 // instantiation ran 40 % behind the plain one); the few freshly reset maps drop what they read
                 if (MODE == FM_STEP) v = reinterpret_cast<const float4*>(vis)[q];
                 if (fresh) {                                                // fused reset: v4:112-119 at the placed ball
                     v = make_float4(0.f, 0.f, 0.f, 0.f);
-                    const int rx = rcen[le * 2], ry = rcen[le * 2 + 1];
-                    v.x = update(v.x, c0, rx, ry);
-                    v.y = update(v.y, c0 + 1, rx, ry);
-                    v.z = update(v.z, c0 + 2, rx, ry);
-                    v.w = update(v.w, c0 + 3, rx, ry);
+                    if (!V5) {                                              // v5:130 restarts from zeros, no window
+                        const int rx = rcen[le * 2], ry = rcen[le * 2 + 1];
+                        v.x = update(v.x, c0, rx, ry);
+                        v.y = update(v.y, c0 + 1, rx, ry);
+                        v.z = update(v.z, c0 + 2, rx, ry);
+                        v.w = update(v.w, c0 + 3, rx, ry);
+                    }
                 }
-                if (!(V5 && MODE == FM_RESET) && !nostep) {                 // v5 adds no window at reset
+                if (!(V5 && MODE == FM_RESET) && !nostep && !(V5 && MODE == FM_STEP && !upd)) {   // v5 adds no window at reset
                     v.x = update(v.x, c0, cx, cy);
                     v.y = update(v.y, c0 + 1, cx, cy);
                     v.z = update(v.z, c0 + 2, cx, cy);
@@ -540,11 +609,12 @@ __global__ __launch_bounds__(LMAZE_BLOCK) void foveal_kernel(const FovealArgs a)
                 const int c = f - le * CELLS;
                 const int fl = flags[le];
                 const bool skip = fl & 1, upd = fl & 2;
-                if (skip || (V5 && MODE == FM_STEP && !upd)) continue;
                 const bool fresh = MODE == FM_STEP && AR && (fl & 4), nostep = MODE == FM_STEP && AR && (fl & 8);
+                if (skip || (V5 && MODE == FM_STEP && !upd && !fresh)) continue;
                 float v = (MODE == FM_STEP && !fresh) ? vis[f] : 0.0f;
-                if (fresh) v = update(v, c, rcen[le * 2], rcen[le * 2 + 1]);
-                if (!(V5 && MODE == FM_RESET) && !nostep) v = update(v, c, cen[le * 4], cen[le * 4 + 1]);
+                if (fresh && !V5) v = update(v, c, rcen[le * 2], rcen[le * 2 + 1]);
+                if (!(V5 && MODE == FM_RESET) && !nostep && !(V5 && MODE == FM_STEP && !upd))
+                    v = update(v, c, cen[le * 4], cen[le * 4 + 1]);
                 vis[f] = v;
                 keep(le, c, v);
             }
@@ -552,7 +622,7 @@ __global__ __launch_bounds__(LMAZE_BLOCK) void foveal_kernel(const FovealArgs a)
         if (V5 && MODE == FM_STEP) {  // unchanged maps: gather the two windows straight from HBM
             for (int i = tid; i < nb * 2 * W25; i += LMAZE_BLOCK) {
                 const int le = i / (2 * W25);
-                if (flags[le] & 3) continue;
+                if (flags[le] & (AR ? 7 : 3)) continue;     // skipped, streamed, or freshly zeroed (kept by the stream)
                 const int r = i - le * 2 * W25;
                 const int w = r / W25, cell = r - w * W25;
                 const int x = cen[le * 4 + 2 * w] - 2 + cell / FOV, y = cen[le * 4 + 2 * w + 1] - 2 + cell % FOV;
@@ -564,8 +634,12 @@ __global__ __launch_bounds__(LMAZE_BLOCK) void foveal_kernel(const FovealArgs a)
 
     // ---------------- phase 3: render float[nb*C*25], contiguous, 16-byte stores ----------------
     auto element = [&](int le, int rem) -> float {
+        if (!V4) {
+            const int f = le * PERENV + rem;
+            return ((obits[f >> 5] >> (f & 31)) & 1u) ? 1.0f : 0.0f;
+        }
         const int ch = rem / W25, cell = rem - ch * W25;
-        if (V4 && (ch == 2 || ch == 6))   // visit map, sampled live at the current / "previous" window
+        if (ch == 2 || ch == 6)   // visit map, sampled live at the current / "previous" window
             return vwin[le * 2 * W25 + (ch == 2 ? 0 : W25) + cell];
         return ((masks[le * 8 + ch] >> cell) & 1u) ? 1.0f : 0.0f;
     };
@@ -578,16 +652,10 @@ __global__ __launch_bounds__(LMAZE_BLOCK) void foveal_kernel(const FovealArgs a)
         int rem = f - le * PERENV;
         float v[4];
         if (!V4) {
-            // bit planes only (v1, v2): the four floats sit in one 25-cell plane or run into the next one (the
-            // next channel, or channel 0 of the next env): two plane masks, one 32-bit shift per float
-            const int ch0 = rem / W25, cell0 = rem - ch0 * W25;
-            const bool wrap = ch0 + 1 == C;
-            const uint32_t m0 = masks[le * 8 + ch0], m1 = masks[(wrap ? le + 1 : le) * 8 + (wrap ? 0 : ch0 + 1)];
-#pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                const int c = cell0 + k;
-                v[k] = ((c < W25 ? (m0 >> c) : (m1 >> (c - W25))) & 1u) ? 1.0f : 0.0f;
-            }
+            // bit planes only (v1, v2): float f of the workgroup's range is bit f of the string phase 1 left in LDS,
+            // a 16-byte store is nibble q of it -- a dozen VALU instructions per store, no index arithmetic
+            // (masks per plane and a division per float made this loop ALU-bound: 1 210 VALU per wave on v2)
+            nibble_floats(obits, q, v);
         } else {
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
@@ -619,13 +687,8 @@ __global__ __launch_bounds__(LMAZE_BLOCK) void foveal_kernel(const FovealArgs a)
             const int f = q << 2;
             const int le = f / PERLOC;
             if (flags[le] & 1) continue;
-            const int rem = f - le * PERLOC;
             float v[4];
-#pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                const int ch = (rem + k) / W25, cell = (rem + k) - ch * W25;
-                v[k] = ((lmasks[le * 4 + ch] >> cell) & 1u) ? 1.0f : 0.0f;
-            }
+            nibble_floats(obits, q, v);
             reinterpret_cast<float4*>(loc)[q] = make_float4(v[0], v[1], v[2], v[3]);
         }
     }
@@ -782,12 +845,25 @@ static hipError_t launch_foveal_one(const FovealArgs& a, hipStream_t s) {
     // masks 32 B + lmasks 16 B + centres 8 B + flags 4 B + reset centre 4 B per env, row masks, layout characters, visit samples
     size_t lds = (size_t)EPB * 64 + (3 * (size_t)L * a.p.grid + 2 * (size_t)a.p.grid) * 8 + (size_t)((L * cells + 15) & ~15);
     if (VARIANT == LMAZE_VARIANT_V4 || VARIANT == LMAZE_VARIANT_V5) lds += (size_t)EPB * 2 * W25 * 4;
+    {   // the bit string of the 0/1 planes (v1, v2: obs; v5/v6: obs_local), see foveal_kernel
+        const int per = VARIANT == LMAZE_VARIANT_V1 ? 4 * W25 : (VARIANT == LMAZE_VARIANT_V2 ? 5 * W25 : 4 * W25);
+        lds += (((size_t)EPB * per + 31) / 32 + 1) * 4 + 16;
+    }
     const int64_t blocks = (a.n + EPB - 1) / EPB;
+    if (!grid_ok(blocks)) return hipErrorInvalidConfiguration;
     FovealArgs b = a;
     const int C = VARIANT == LMAZE_VARIANT_V1 ? 4 : (VARIANT == LMAZE_VARIANT_V2 ? 5 : 7);
     b.nt = (size_t)a.n * C * W25 * 4 > ((size_t)192 << 20);
+    // launch_hint bits 0-3: at most that many workgroups resident per CU, by padding the dynamic LDS (160 KiB per
+    // CU), as the step kernel does in its streaming regime (lmaze_step.hip launch_shared); 0 = no cap
+    const int per_cu = a.p.launch_hint & 15;
+    if (MODE == FM_STEP && per_cu >= 1 && per_cu <= 8) {
+        const size_t cap = 160 * 1024;
+        const size_t want = ((cap / per_cu + cap / (per_cu + 1)) / 2) & ~(size_t)255;   // between the two thresholds
+        if (want > lds && want <= 64 * 1024) lds = want;
+    }
     const dim3 grid((unsigned)blocks), block(LMAZE_BLOCK);
-    if constexpr (MODE == FM_STEP && VARIANT != LMAZE_VARIANT_V5) {
+    if constexpr (MODE == FM_STEP) {
         if (a.auto_reset) {
             if (a.p.grid == 18) hipLaunchKernelGGL((foveal_kernel<VARIANT, MODE, EPB, 18, true>), grid, block, lds, s, b);
             else if (a.p.grid == 14) hipLaunchKernelGGL((foveal_kernel<VARIANT, MODE, EPB, 14, true>), grid, block, lds, s, b);
@@ -801,9 +877,31 @@ static hipError_t launch_foveal_one(const FovealArgs& a, hipStream_t s) {
     return hipGetLastError();
 }
 
+// launch_hint bits 4-7 (plain step only): envs per workgroup, 2: 32 ... 5: 256; anything else = the default below
+template <int VARIANT>
+static bool launch_step_hinted(const FovealArgs& a, hipStream_t s, hipError_t& rc) {
+    if (a.auto_reset) return false;
+    switch ((a.p.launch_hint >> 4) & 15) {
+        case 2: rc = launch_foveal_one<VARIANT, FM_STEP, 32>(a, s); return true;
+        case 3: rc = launch_foveal_one<VARIANT, FM_STEP, 64>(a, s); return true;
+        case 4: rc = launch_foveal_one<VARIANT, FM_STEP, 128>(a, s); return true;
+        case 5: rc = launch_foveal_one<VARIANT, FM_STEP, 256>(a, s); return true;
+        default: return false;
+    }
+}
+
 template <int MODE>
 static hipError_t launch_foveal_mode(const FovealArgs& a, hipStream_t s) {
     if (a.n == 0) return hipSuccess;
+    if (MODE == FM_STEP) {
+        hipError_t rc = hipSuccess;
+        switch (a.p.variant) {
+            case LMAZE_VARIANT_V1: if (launch_step_hinted<LMAZE_VARIANT_V1>(a, s, rc)) return rc; break;
+            case LMAZE_VARIANT_V2: if (launch_step_hinted<LMAZE_VARIANT_V2>(a, s, rc)) return rc; break;
+            case LMAZE_VARIANT_V4: if (launch_step_hinted<LMAZE_VARIANT_V4>(a, s, rc)) return rc; break;
+            default: if (launch_step_hinted<LMAZE_VARIANT_V5>(a, s, rc)) return rc; break;
+        }
+    }
     switch (a.p.variant) {
         // envs per workgroup, measured warm at 1M envs (TB/s of algorithmic traffic, 256 / 128 / 64 envs):
         //   v1 (400 B of observation per env)  5.9-6.0 / 6.1 / 6.7-6.8      v2 (500 B)  5.9 / 6.1 / 5.8
@@ -827,7 +925,8 @@ static int check_foveal(const LmazeFovealParams* p, const uint8_t* layouts, cons
         return LMAZE_E_VARIANT;
     if (p->grid < FOV || p->grid > LMAZE_MAX_GRID) return LMAZE_E_GRID;
     if (p->n_layouts < 1 || p->n_layouts > LMAZE_MAX_LAYOUTS) return LMAZE_E_LAYOUT;
-    if (n < 0 || n > ((int64_t)1 << 40)) return LMAZE_E_COUNT;
+    if (n < 0 || n > LMAZE_MAX_ENVS) return LMAZE_E_COUNT;
+    if (p->launch_hint & ~0xff) return LMAZE_E_LAYOUT;
     if (v56) {
         if (!b->fgoal_xy || !b->foveal_step_count || !b->foveal_reward || !b->foveal_done || !b->visit || !b->ball1_xy ||
             !b->fovea_xy || !b->last_xy || !b->foveal_goal || !b->obs_local)
@@ -849,6 +948,7 @@ static FovealArgs make_foveal_args(const LmazeFovealParams* p, const uint8_t* la
     a.b = *b;
     a.layouts = layouts;
     a.action = nullptr;
+    a.goal2 = nullptr;
     a.mask = nullptr;
     a.n = n;
     a.place = 0;
@@ -889,6 +989,27 @@ int lmaze_foveal_step_autoreset(const LmazeFovealParams* params, const uint8_t* 
     if (bad_epoch_words(epoch_in_dev, epoch_out_dev)) return LMAZE_E_ALIGN;
     FovealArgs a = make_foveal_args(params, layouts, bufs, n);
     a.action = action;
+    a.auto_reset = 1;
+    a.seed = seed;
+    a.epoch = epoch;
+    a.env_base = env_base;
+    a.epoch_in = epoch_in_dev;
+    a.epoch_out = epoch_out_dev;
+    return (int)launch_foveal_mode<FM_STEP>(a, (hipStream_t)stream);
+}
+
+int lmaze_v5_hier_step(const LmazeFovealParams* params, const uint8_t* layouts, const int32_t* action,
+                       const int32_t* planner_goal, const LmazeFovealBuffers* bufs, int64_t n, uint64_t seed,
+                       uint64_t epoch, int64_t env_base, const uint64_t* epoch_in_dev, uint64_t* epoch_out_dev,
+                       void* stream) {
+    int rc = check_foveal(params, layouts, bufs, n);
+    if (rc) return rc;
+    if (params->variant != LMAZE_VARIANT_V5 && params->variant != LMAZE_VARIANT_V6) return LMAZE_E_VARIANT;
+    if (!action || !planner_goal) return LMAZE_E_NULL;
+    if (bad_epoch_words(epoch_in_dev, epoch_out_dev)) return LMAZE_E_ALIGN;
+    FovealArgs a = make_foveal_args(params, layouts, bufs, n);
+    a.action = action;
+    a.goal2 = planner_goal;
     a.auto_reset = 1;
     a.seed = seed;
     a.epoch = epoch;
@@ -949,6 +1070,7 @@ int lmaze_v6_safe_foveal_goal(const LmazeFovealParams* params, const uint8_t* la
     a.seed = seed;
     a.epoch = epoch;
     a.env_base = env_base;
+    if (!grid_ok((n + LMAZE_BLOCK - 1) / LMAZE_BLOCK)) return (int)hipErrorInvalidConfiguration;
     hipLaunchKernelGGL(safe_goal_kernel, dim3((unsigned)((n + LMAZE_BLOCK - 1) / LMAZE_BLOCK)), dim3(LMAZE_BLOCK), 0,
                        (hipStream_t)stream, a, out_goal);
     return (int)hipGetLastError();
@@ -959,7 +1081,7 @@ int lmaze_expand_planes(const float* planes, int32_t channels, int32_t g, int32_
     if (!planes || !out) return LMAZE_E_NULL;
     if (g < 1 || g > LMAZE_MAX_GRID) return LMAZE_E_GRID;
     if (expansion < 1 || expansion > 16 || channels < 1 || channels > 16) return LMAZE_E_EXPANSION;
-    if (n < 0 || n > ((int64_t)1 << 40)) return LMAZE_E_COUNT;
+    if (n < 0 || n > LMAZE_MAX_ENVS) return LMAZE_E_COUNT;
     if (((uintptr_t)out & 15) || ((uintptr_t)planes & 3)) return LMAZE_E_ALIGN;
     if (n == 0) return 0;
     ExpandPlanesArgs a;
@@ -974,7 +1096,7 @@ int lmaze_expand_planes(const float* planes, int32_t channels, int32_t g, int32_
         const int chunk = 12288;
         const int64_t total = n * (int64_t)channels * (FOV * 7) * (FOV * 7);
         const int64_t chunks = (total + chunk - 1) / chunk;
-        if (chunks <= 0x7fffffff) {
+        if (grid_ok(chunks)) {
             size_t lds = ((size_t)(chunk / ((FOV * 7) * (FOV * 7)) + 3) * W25 * 4 + 15) & ~(size_t)15;   // planes touched + one of slack
             if (total * 4 > ((int64_t)192 << 20)) {
                 const size_t cap = 160 * 1024, want = ((cap / 2 + cap / 3) / 2) & ~(size_t)255;      // 2 workgroups per CU

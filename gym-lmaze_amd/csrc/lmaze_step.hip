@@ -588,6 +588,7 @@ static hipError_t launch_shared(const StepArgs& a, hipStream_t s) {
     int m = (a.launch_hint >> 4) & 15;
     if (m == 0) m = nt ? 2 : 1;
     const int64_t grid = (blocks + m - 1) / m;
+    if (!grid_ok(grid)) return hipErrorInvalidConfiguration;
     if (nt)
         hipLaunchKernelGGL((step_shared_kernel<GT, VARIANT, DO_STEP, EPB, true>), dim3((unsigned)grid),
                            dim3(LMAZE_BLOCK), lds, s, a);
@@ -607,6 +608,7 @@ static hipError_t launch_perenv_wave(const StepArgs& a, hipStream_t s) {
     const int64_t per_block = (int64_t)b.envs_per_block * (LMAZE_BLOCK / 64);
     const int64_t blocks = (a.n + per_block - 1) / per_block;
     const bool nt = a.obs != nullptr && (size_t)a.n * G * G * 4 > kNonTemporalObsBytes;
+    if (!grid_ok(blocks)) return hipErrorInvalidConfiguration;
     if (nt)
         hipLaunchKernelGGL((step_perenv_wave_kernel<G, VARIANT, DO_STEP, true>), dim3((unsigned)blocks),
                            dim3(LMAZE_BLOCK), 0, s, b);
@@ -628,6 +630,7 @@ static hipError_t launch_perenv(const StepArgs& a, hipStream_t s) {
     StepArgs b = a;
     b.envs_per_block = perenv_envs_per_block(a.grid);
     const int64_t blocks = (a.n + b.envs_per_block - 1) / b.envs_per_block;
+    if (!grid_ok(blocks)) return hipErrorInvalidConfiguration;
     hipLaunchKernelGGL((step_perenv_kernel<GT, VARIANT, DO_STEP>), dim3((unsigned)blocks), dim3(LMAZE_BLOCK),
                        perenv_lds_bytes(a.grid, b.envs_per_block), s, b);
     return hipGetLastError();

@@ -106,7 +106,7 @@ class LmazeFovealVecEnv(object):
 
         r = spec["rewards"]
         self.params = _abi.LmazeFovealParams(spec["id"], G, self.n_layouts, spec["step_limit"],
-                                             spec["foveal_step_limit"], r[0], r[1], r[2])
+                                             spec["foveal_step_limit"], r[0], r[1], r[2], 0)
         self._pp = C.byref(self.params)
         self.bufs = _abi.LmazeFovealBuffers(
             self.ball_xy.data_ptr(), self.goal_xy.data_ptr(), self.fgoal_xy.data_ptr(), self.layout_id.data_ptr(),
@@ -188,6 +188,47 @@ class LmazeFovealVecEnv(object):
                                                 self._stream())
         _abi.check("lmaze_foveal_step", rc)
         return self.obs, self.reward, self.done, actions
+
+    def step_raw(self, action_ptr, auto_reset=False):
+        """step() on a raw device pointer to int32[N] actions (rollouts over a pre-generated [T,N] tensor)."""
+        with self._guard():
+            if auto_reset:
+                if self._two_level:
+                    raise ValueError("auto_reset is not defined for v5/v6 (use hier_step)")
+                rc = _abi.lib.lmaze_foveal_step_autoreset(self._pp, self._p_layouts, action_ptr, self._pb, self.num_envs,
+                                                          self.seed & (2 ** 64 - 1), self._epoch, self.env_base,
+                                                          None, None, self._stream())
+                self._epoch += 1
+            else:
+                rc = _abi.lib.lmaze_foveal_step(self._pp, self._p_layouts, action_ptr, self._pb, self.num_envs, self._stream())
+        _abi.check("lmaze_foveal_step", rc)
+
+    def hier_step(self, actions, goals, epoch_slot=None):
+        """v5/v6: the two-level loop around step() as ONE launch (lmaze_v5_hier_step) -- reset() for the envs whose
+        globalDone (`done`) is set on entry, plannerStep(goals[i]) for those whose localDone (`foveal_done`) is set
+        or that were just reset, then step(actions[i]) for everybody.  Bit-identical to reset(mask=done),
+        planner_step(goals, mask=done | foveal_done), step(actions).  Returns (obs, obs_local, reward,
+        foveal_reward, done, foveal_done) -- the tensors of the reference's 8-tuple (lmaze_env_v5.py:285-292)."""
+        a = self._as_i32(actions, self.num_envs)
+        g = self._as_i32(goals, self.num_envs)
+        self.hier_step_raw(a.data_ptr(), g.data_ptr(), epoch_slot)
+        return self.obs, self.obs_local, self.reward, self.foveal_reward, self.done, self.foveal_done
+
+    def hier_step_raw(self, action_ptr, goal_ptr, epoch_slot=None):
+        if not self._two_level:
+            raise ValueError("hier_step is the two-level loop of v5/v6")
+        with self._guard():
+            if epoch_slot is None:
+                epoch, e_in, e_out = self._epoch, None, None
+                self._epoch += 1
+            else:
+                if self._epoch_words is None:
+                    self._epoch_words = torch.zeros(2, dtype=torch.int64, device=self.device)
+                base, t = self._epoch_words.data_ptr(), int(epoch_slot)
+                epoch, e_in, e_out = 0, base + 8 * (t & 1), base + 8 * ((t + 1) & 1)
+            rc = _abi.lib.lmaze_v5_hier_step(self._pp, self._p_layouts, action_ptr, goal_ptr, self._pb, self.num_envs,
+                                             self.seed & (2 ** 64 - 1), epoch, self.env_base, e_in, e_out, self._stream())
+        _abi.check("lmaze_v5_hier_step", rc)
 
     def reset(self, mask=None, place=True, seed=None):
         """Masked reset; place=False keeps the caller's ball/goal/layout_id (set_state)."""

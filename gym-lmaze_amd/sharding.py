@@ -38,3 +38,16 @@ def sum_over_ranks(values, device=None):
     if dist.is_available() and dist.is_initialized():
         dist.all_reduce(t, op=dist.ReduceOp.SUM)
     return t
+
+
+def gather_over_ranks(value, device=None):
+    """The per-rank scalar of every rank, in rank order (the bench reports min / max of the per-rank step time
+    so that a straggler shows).  No process group -> [value]."""
+    import torch
+    import torch.distributed as dist
+    if not (dist.is_available() and dist.is_initialized()):
+        return [float(value)]
+    t = torch.tensor([float(value)], dtype=torch.float64, device=device if device is not None else "cpu")
+    out = [torch.zeros_like(t) for _ in range(dist.get_world_size())]
+    dist.all_gather(out, t)
+    return [float(x.item()) for x in out]

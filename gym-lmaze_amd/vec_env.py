@@ -8,12 +8,15 @@ masked reset) runs in liblmaze_hip.so; there is no CPU implementation in this pa
 Reference semantics: gym_lmaze/envs/lmaze_env.py (v0) and lmaze_env_v3.py (v3).
 """
 import ctypes as C
+import logging
 
 import numpy as np
 import torch
 
 from . import _abi
 from . import layouts as L
+
+_log = logging.getLogger("gym_lmaze_amd")
 
 # per-variant constants the reference hard-codes in __init__
 VARIANTS = {
@@ -54,14 +57,18 @@ class LmazeVecEnv(object):
     per_env_layouts   uint8[N,G,G] (numpy or torch): every env has its own maze
     env_base          global index of local env 0 when the batch is one shard of a larger
                       one (keys the reset draws; see include/lmaze.h lmaze_reset)
-    online_autotune   large shared-layout batches only (the streaming regime): time the launch policies on
-                      the caller's own first few hundred steps, in the caller's own loop, and keep the
-                      fastest (see OnlineTuner); autotune() or set_launch_policy() switch it off
+    online_autotune   OPT-IN (default False: the library's default launch policy, nothing timed).  True, on
+                      large shared-layout batches only (the streaming regime): time the launch policies on
+                      the caller's own first ~250 steps, in the caller's own loop -- those steps cycle through 12
+                      policies, each bracketed by an event pair, up to 20 % slower -- and keep the fastest
+                      (see OnlineTuner; `tuning_progress()` reports where it is, `tuned_policy` the winner; one
+                      log line when it starts and one when it ends); autotune() or set_launch_policy() switch it off.
+                      Results never depend on the policy.
     """
 
     def __init__(self, num_envs, variant="v0", layout=None, per_env_layouts=None, device=None,
                  expansion=None, step_limit=None, rewards=None, seed=0, env_base=0, validate=True,
-                 online_autotune=True):
+                 online_autotune=False):
         if variant not in VARIANTS:
             raise ValueError("unknown variant %r (have %s)" % (variant, sorted(VARIANTS)))
         spec = VARIANTS[variant]
@@ -134,6 +141,9 @@ class LmazeVecEnv(object):
         self._bind_pointers()
         streaming = self.layout_mode == _abi.LAYOUT_SHARED and N * G * G * 4 > (192 << 20)
         self._tuner = OnlineTuner(self.CANDIDATES) if (online_autotune and streaming) else None
+        if self._tuner is not None:
+            _log.info("gym-lmaze_amd: online launch-policy tuning on for the next ~%d steps of this %d-env batch",
+                      self._tuner.warm + self._tuner.samples * len(self.CANDIDATES), N)
 
         if not self._is_v3:
             # v0 looks the goal up once from the layout (lmaze_env.py:100-102): first 'X', row-major
@@ -216,6 +226,13 @@ class LmazeVecEnv(object):
         self._epoch_words[0:1].fill_(self._epoch)
         self._epoch += int(n_launches)
 
+    def tuning_progress(self):
+        """None when no online tuning is running, else (timed launches collected, launches needed)."""
+        t = self._tuner
+        if t is None:
+            return None
+        return sum(len(v) for v in t.timings.values()), t.samples * len(t.candidates)
+
     def set_launch_policy(self, per_cu, chunks=1):
         """Fix the launch policy (workgroups per CU, chunks per workgroup) and stop any tuning."""
         self.params.launch_hint = self.launch_hint_of(per_cu, chunks)
@@ -234,6 +251,7 @@ class LmazeVecEnv(object):
             if best is not None:                     # every candidate has its samples: keep the fastest
                 self.params.launch_hint = self.launch_hint_of(*best)
                 self.tuned_policy, self._tuner = best, None
+                _log.info("gym-lmaze_amd: online tuning done, launch policy (workgroups per CU, chunks) = %s", best)
             return
         self._launch_step_raw(action_ptr, obs_ptr, auto_reset, epoch_slot)
 

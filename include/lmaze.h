@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define LMAZE_ABI_VERSION 2
+#define LMAZE_ABI_VERSION 3
 
 /* which reference class the transition rules come from */
 enum {
@@ -62,6 +62,10 @@ enum {
 };
 
 #define LMAZE_MAX_GRID 64
+/* most envs one call accepts (LMAZE_E_COUNT beyond).  A launch is further limited to 2^24 - 1 workgroups of 256
+ * threads (HIP: grid * block < 2^32); a count whose launch would need more -- the per-env-layout kernels take 4
+ * envs per workgroup, i.e. 2^26 envs -- is refused with hipErrorInvalidConfiguration, never truncated. */
+#define LMAZE_MAX_ENVS ((int64_t)1 << 30)
 #define LMAZE_MAX_CHANNELS 8
 
 /* Constants the reference hard-codes in __init__ (v0:17-23, v3:76-99). */
@@ -236,6 +240,10 @@ typedef struct LmazeFovealParams {
     float reward_wall;          /* negativeNominal -1.0                                                 */
     float reward_move;          /* positiveNominal v1 +0.01 (v1:28); v2/v4 -0.01 (v2:47)               */
     float reward_goal;          /* positiveFull    v1 1.0 (v1:29);   v2/v4 100.0                       */
+    int32_t launch_hint;        /* 0 = library default launch policy; else bits 0-3 = workgroups per CU
+                                   (1..8, 0 = no cap), bits 4-7 = log2(envs per workgroup) - 4 + 1, i.e.
+                                   1: 16 envs ... 5: 256 envs (0 = default).  Performance only, never
+                                   results (lmaze_foveal.hip launch_foveal_mode); other bits 0.          */
 } LmazeFovealParams;
 
 /* Device pointers, one element per env; entries a variant does not use may be NULL. */
@@ -321,6 +329,23 @@ int lmaze_v1_set_foveal_goal(const LmazeFovealParams* params, const uint8_t* lay
  */
 int lmaze_v5_planner_step(const LmazeFovealParams* params, const uint8_t* layouts, const int32_t* goal,
                           const uint8_t* mask, const LmazeFovealBuffers* bufs, int64_t n, void* stream);
+
+/*
+ * The two-level loop of v5/v6 as ONE launch per env-step: what a caller of the reference does around step() --
+ *     if globalDone: reset()                       (v5:104-150)
+ *     if localDone or it was just reset: plannerStep(goal)   (v5:158-182)
+ *     step(action)                                 (v5:187-292)
+ * -- for every env, keyed on the done[i] / foveal_done[i] flags ON ENTRY.  Bit-identical to
+ * lmaze_foveal_reset(mask = done, place = 1, seed, epoch, env_base), then lmaze_v5_planner_step(planner_goal,
+ * mask = done | foveal_done), then lmaze_foveal_step(action): state, visit map, obs and obs_local.  planner_goal
+ * int32[N] is read for every env and used by those that take the plannerStep (a value outside 0..24 skips that
+ * env's plannerStep, as lmaze_v5_planner_step does).  epoch_in_dev / epoch_out_dev: the device-resident epoch, as
+ * for lmaze_step_v0_autoreset.
+ */
+int lmaze_v5_hier_step(const LmazeFovealParams* params, const uint8_t* layouts, const int32_t* action,
+                       const int32_t* planner_goal, const LmazeFovealBuffers* bufs, int64_t n, uint64_t seed,
+                       uint64_t epoch, int64_t env_base, const uint64_t* epoch_in_dev, uint64_t* epoch_out_dev,
+                       void* stream);
 
 /*
  * v6 safeFovealGoal() (v6:505-523): for every env one window cell index 0..24 drawn uniformly from the

@@ -9,6 +9,7 @@
  */
 #include <stdint.h>
 #include <stddef.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include "../include/lmaze.h"
@@ -463,6 +464,31 @@ int lmaze_oracle_v5_reset(const LmazeFovealParams* p, const uint8_t* layouts, co
         fov_obs_v5(lay, G, bx, by, bx, by, b->goal_xy[2 * e], b->goal_xy[2 * e + 1], 12, visit, b->obs + (size_t)e * 7 * W25);
     }
     return 0;
+}
+
+/* The two-level loop around step() (include/lmaze.h lmaze_v5_hier_step), by composition of the three functions
+ * above, each pinned on its own against the reference's recorded rollouts: reset() where globalDone is set on
+ * entry (v5:104-150), plannerStep(goal) where localDone is set or the env was just reset (v5:158-182), step(action)
+ * for everybody (v5:187-292). */
+int lmaze_oracle_v5_hier_step(const LmazeFovealParams* p, const uint8_t* layouts, const int32_t* action,
+                              const int32_t* planner_goal, const LmazeFovealBuffers* b, int64_t n, uint64_t seed,
+                              uint64_t epoch, int64_t env_base) {
+    int rc = check_v56(p, layouts, b, n);
+    if (rc) return rc;
+    if (!action || !planner_goal) return LMAZE_E_NULL;
+    if (n == 0) return 0;
+    uint8_t* m = (uint8_t*)malloc((size_t)2 * (size_t)n);
+    if (!m) return LMAZE_E_COUNT;
+    uint8_t *m_reset = m, *m_plan = m + n;
+    for (int64_t e = 0; e < n; ++e) {
+        m_reset[e] = b->done[e] != 0;
+        m_plan[e] = m_reset[e] || b->foveal_done[e] != 0;
+    }
+    rc = lmaze_oracle_v5_reset(p, layouts, m_reset, 1, seed, epoch, env_base, b, n);
+    if (!rc) rc = lmaze_oracle_v5_planner_step(p, layouts, planner_goal, m_plan, b, n);
+    if (!rc) rc = lmaze_oracle_v5_step(p, layouts, action, b, n);
+    free(m);
+    return rc;
 }
 
 /* v6:505-523 */

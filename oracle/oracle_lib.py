@@ -140,7 +140,7 @@ FOVEAL_CHANNELS = {VARIANT_V1: 4, VARIANT_V2: 5, VARIANT_V4: 7, VARIANT_V5: 7, V
 class FovealParams(C.Structure):
     _fields_ = [("variant", C.c_int32), ("grid", C.c_int32), ("n_layouts", C.c_int32), ("step_limit", C.c_int32),
                 ("foveal_step_limit", C.c_int32), ("reward_wall", C.c_float), ("reward_move", C.c_float),
-                ("reward_goal", C.c_float)]
+                ("reward_goal", C.c_float), ("launch_hint", C.c_int32)]
 
 
 class FovealBuffers(C.Structure):
@@ -152,10 +152,10 @@ class FovealBuffers(C.Structure):
 
 def foveal_params(variant, grid, n_layouts):
     if variant == VARIANT_V1:      # lmaze_env_v1.py:22-29
-        return FovealParams(variant, grid, n_layouts, 200, 10, -1.0, 0.01, 1.0)
+        return FovealParams(variant, grid, n_layouts, 200, 10, -1.0, 0.01, 1.0, 0)
     if variant in (VARIANT_V5, VARIANT_V6):   # lmaze_env_v5.py:45-49
-        return FovealParams(variant, grid, n_layouts, 10, 50, -1.0, -0.01, 100.0)
-    return FovealParams(variant, grid, n_layouts, 50, 0, -1.0, -0.01, 100.0)   # lmaze_env_v2.py:43-49
+        return FovealParams(variant, grid, n_layouts, 10, 50, -1.0, -0.01, 100.0, 0)
+    return FovealParams(variant, grid, n_layouts, 50, 0, -1.0, -0.01, 100.0, 0)   # lmaze_env_v2.py:43-49
 
 
 class FovealState(object):
@@ -245,6 +245,17 @@ def v5_reset(p, layouts, mask, place, seed, epoch, st, env_base=0):
                                      C.c_uint64(seed), C.c_uint64(epoch), C.c_int64(env_base), C.byref(b), C.c_int64(st.n))
     if rc:
         raise RuntimeError("lmaze_oracle_v5_reset -> %d" % rc)
+
+
+def v5_hier_step(p, layouts, action, goal, seed, epoch, st, env_base=0):
+    """reset where done, plannerStep(goal) where localDone or just reset, step(action): the composition the
+    fused HIP launch lmaze_v5_hier_step is checked against."""
+    b = st.struct()
+    goal = np.ascontiguousarray(goal, dtype=np.int32)
+    rc = lib().lmaze_oracle_v5_hier_step(C.byref(p), _p(layouts, C.c_uint8), _p(action, C.c_int32), _p(goal, C.c_int32),
+                                         C.byref(b), C.c_int64(st.n), C.c_uint64(seed), C.c_uint64(epoch), C.c_int64(env_base))
+    if rc:
+        raise RuntimeError("lmaze_oracle_v5_hier_step -> %d" % rc)
 
 
 def v6_safe_foveal_goal(p, layouts, seed, epoch, st, env_base=0):

@@ -40,7 +40,7 @@ def test_header_cites_reference_lines():
 
 
 def test_abi_version_and_errors(abi):
-    assert abi.lib.lmaze_abi_version() == abi.ABI_VERSION == 2
+    assert abi.lib.lmaze_abi_version() == abi.ABI_VERSION == 3
     assert abi.strerror(0) == "ok"
     p = abi.make_params(abi.VARIANT_V0, 12, abi.LAYOUT_SHARED, 100, -1.0, -0.01, 100.0)
     # NULL pointers / bad sizes are rejected before anything is launched
@@ -54,6 +54,9 @@ def test_abi_version_and_errors(abi):
     m = (C.c_int32 * 4)(1, 2, 4, 8)
     assert abi.lib.lmaze_render_expanded(16, 12, 99, m, 4, 16, 1, None) == -7
     assert "aligned" in abi.strerror(-6)
+    # a count no launch could cover is refused, never narrowed into a truncated grid (include/lmaze.h LMAZE_MAX_ENVS)
+    assert abi.lib.lmaze_step_v0(C.byref(p), 16, 16, 16, 16, 16, 16, None, None, (1 << 30) + 1, None) == -5
+    assert abi.lib.lmaze_observe(C.byref(p), 16, 16, None, 16, 1 << 40, None) == -5
 
 
 def test_params_struct_layout(abi):

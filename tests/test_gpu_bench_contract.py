@@ -12,9 +12,9 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def _run(*flags):
+def _run(*flags, env=None):
     out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), *flags], capture_output=True, text=True,
-                         timeout=900, cwd=ROOT)
+                         timeout=900, cwd=ROOT, env=env)
     assert out.returncode == 0, out.stderr[-3000:]
     lines = [l for l in out.stdout.splitlines() if l.strip()]
     assert len(lines) == 1, out.stdout[:2000]
@@ -27,6 +27,7 @@ def _run(*flags):
     ("--workload", "c5", "--envs", "65536", "--steps", "6", "--warmup", "2", "--no-cpu-baseline"),
     ("--workload", "v2", "--envs", "262144", "--steps", "8", "--warmup", "2", "--cpu-baseline-seconds", "0.5"),
     ("--workload", "c2", "--graph", "--auto-reset", "--steps", "10", "--warmup", "2", "--no-cpu-baseline"),
+    ("--workload", "v5", "--envs", "262144", "--steps", "30", "--warmup", "12", "--cpu-baseline-seconds", "0.5"),
 ])
 def test_bench_line(flags):
     d = _run(*flags)
@@ -43,13 +44,57 @@ def test_bench_line(flags):
     assert r["bound"] == "hbm" and r["unit"] == "GB/s" and r["peak"] == 8000.0
     assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-12 and 0.0 < r["frac"] < 1.0
     assert abs(r["achieved"] - envs * r["bytes_per_env_step"] / (r["kernel_ms_avg"] * 1e-3) / 1e9) <= 1e-6 * r["achieved"]
-    assert r["traffic"] is None or r["traffic"] >= 0.9 * envs * r["bytes_per_env_step"]
+    assert r["traffic"] is None or r["traffic"] >= 0.9 * (envs // d["n_gpus"]) * r["bytes_per_env_step"]
     assert set(r["measured_ceiling"]) >= {"fill", "copy", "unit"}
     if "--no-cpu-baseline" in flags:
         assert "cpu_baseline" not in d
     else:
         c = d["cpu_baseline"]
         assert c["kind"] == "port" and c["unit"] == "env-steps/s" and c["cores"] >= 1 and c["value"] > 0 and c["sample"]
+        assert c["single_thread"]["cores"] == 1 and c["single_thread"]["value"] > 0 and c["single_thread"]["kind"] == "port"
+        ri = c["reference_interpreter"]
+        assert ri["kind"] == "reference" and ri["value"] > 0 and "NOT this box" in ri["sample"]
+        if "--workload" not in flags or flags[flags.index("--workload") + 1].startswith("c"):
+            assert c["numpy_vectorised"]["value"] > 0
+    # the regime does not depend on --steps: the action ring is larger than the Infinity Cache (c2: SURVEY's 256 rows)
+    rows = int(d["config"]["actions"].split("int32[")[1].split(",")[0])
+    wl = flags[flags.index("--workload") + 1] if "--workload" in flags else "c3"
+    assert rows == 256 if wl == "c2" else rows * d["config"]["envs_per_gpu"] * 4 >= (320 << 20)
+    assert d["per_rank_ms_per_step"]["min"] <= d["per_rank_ms_per_step"]["max"] and len(d["per_rank_ms_per_step"]["all"]) == 1
+    assert d["config"]["world_size_seen"] == 1 and "traffic_source" in r and "perenv_kernel" in d["config"]
+    assert (r["traffic"] is None) == (r["traffic_source"] is None)
+    if wl == "c5":
+        assert "wave/register-tiled" in d["config"]["perenv_kernel"]
+    if wl == "v5":
+        ev = d["config"]["v5_events_in_timed_steps"]
+        total = d["config"]["envs_per_gpu"] * d["steps"]
+        assert ev["resets"] + ev["visit_updates"] + ev["window_gathers"] == total and 0 < ev["resets"] < ev["planner_steps"] < total
+        assert 0.05 < d["config"]["local_done_rate"] < 0.6           # the natural rate, not 1.0
     if "--workload" not in flags:
         assert d["metric"].startswith("env steps/sec (whole node), 1M parallel 11x11 mazes")
         assert d["config"]["envs_per_gpu"] == 1 << 20 and d["config"]["grid"] == 11 and r["bytes_per_env_step"] == 521
+
+
+def test_plain_gpus_2_launches_its_own_ranks():
+    """`python bench.py --gpus 2` from a plain shell (no torchrun): the parent spawns two ranks before touching the
+    GPU; here they share the one visible device and meet over gloo (the rehearsal backend), on a real node each
+    takes its own device over RCCL."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT")}
+    env["LMAZE_BENCH_BACKEND"] = "gloo"
+    d = _run("--gpus", "2", "--steps", "20", "--warmup", "5", "--envs", "262144", "--no-cpu-baseline", env=env)
+    assert d["n_gpus"] == 2 and d["config"]["world_size_seen"] == 2 and d["config"]["global_envs"] == 2 * 262144
+    assert "self" in d["config"]["launcher"] and "REHEARSAL" in d["config"]["collective_backend"]
+    pr = d["per_rank_ms_per_step"]
+    assert len(pr["all"]) == 2 and pr["min"] <= pr["max"] and abs(pr["max"] - d["ms_per_step"]) < 1e-9
+    assert abs(d["value"] - d["config"]["global_envs"] * d["steps"] / (d["ms_per_step"] * 1e-3 * d["steps"])) <= 1e-6 * d["value"]
+    assert "cpu_baseline" not in d
+
+
+def test_torchrun_entry_still_works():
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1",
+                          "--master-addr", "127.0.0.1", "--master-port", "29533", os.path.join(ROOT, "bench.py"),
+                          "--gpus", "1", "--steps", "10", "--warmup", "3", "--envs", "262144", "--no-cpu-baseline"],
+                         capture_output=True, text=True, timeout=900, cwd=ROOT)
+    assert out.returncode == 0, out.stderr[-3000:]
+    d = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
+    assert d["n_gpus"] == 1 and d["config"]["collective_backend"] == "rccl" and "external" in d["config"]["launcher"]

@@ -498,3 +498,124 @@ def test_four_million_v4_envs_tail_against_the_oracle():
         assert (f32_bits(h["reward"][sl]) == f32_bits(st.reward)).all()
         assert (_bits(_np(env.visit[sl])) == _bits(st.visit)).all()
         assert (_bits(_np(env.obs[sl])) == _bits(st.obs)).all()
+
+
+# ---------------------------------------------------------------- v5/v6: the two-level loop as one launch
+@pytest.mark.parametrize("N", [1, 37, 3000])
+def test_v5_hier_step_equals_reset_planner_step_and_the_oracle(N):
+    """lmaze_v5_hier_step == lmaze_foveal_reset(mask=done) + lmaze_v5_planner_step(mask=done|localDone) +
+    lmaze_foveal_step, and == the oracle's composition of its three pinned functions, every step: state,
+    visit map, both observations.  Planner goals include out-of-range ids (the env's plannerStep is skipped)."""
+    seed, base = 40 + N, 77
+    fused = PKG.LmazeFovealVecEnv(N, variant="v5", seed=seed, env_base=base)
+    split = PKG.LmazeFovealVecEnv(N, variant="v5", seed=seed, env_base=base)
+    lay = _np(fused.layouts)
+    p = O.foveal_params(O.VARIANT_V5, fused.grid, fused.n_layouts)
+    st = O.FovealState(O.VARIANT_V5, N, fused.grid)
+    O.v5_reset(p, lay, None, 1, seed, 0, st, env_base=base)
+    for e in (fused, split):
+        e.foveal_done.fill_(True)            # the loop starts with a plannerStep for everybody
+    st.foveal_done[:] = 1
+    st.obs_local[...] = _np(fused.obs_local)
+    _same56(fused, st, "start")
+    rs = np.random.RandomState(N)
+    events = np.zeros(3, np.int64)
+    for t in range(160):
+        a = np.where(rs.rand(N) < 0.95, rs.randint(0, 4, N), rs.randint(-1, 6, N)).astype(np.int32)
+        g = np.where(rs.rand(N) < 0.97, rs.randint(0, 25, N), rs.randint(-2, 28, N)).astype(np.int32)
+        epoch = fused._epoch
+        assert epoch == split._epoch
+        m_reset = _np(split.done).astype(np.uint8)
+        m_plan = m_reset | _np(split.foveal_done).astype(np.uint8)
+        events += (int(m_reset.sum()), int(m_plan.sum()), N)
+        split.reset(mask=torch.from_numpy(m_reset))
+        split.planner_step(g, mask=torch.from_numpy(m_plan))
+        split.step(torch.from_numpy(a))
+        fused.hier_step(torch.from_numpy(a), torch.from_numpy(g))
+        O.v5_hier_step(p, lay, a, g, seed, epoch, st, env_base=base)
+        _same56(fused, st, ("oracle", t))
+        hf, hs = fused.host_state(), split.host_state()
+        for k in hf:
+            assert (hf[k].view(np.uint8) == hs[k].view(np.uint8)).all(), (k, t)
+        for x, y in ((fused.visit, split.visit), (fused.obs, split.obs), (fused.obs_local, split.obs_local)):
+            assert (_bits(_np(x)) == _bits(_np(y))).all(), t
+    if N >= 37:
+        assert events[0] > 0 and events[1] > events[0]      # global episodes ended and restarted; local ones more often
+
+
+def test_v5_hier_step_captured_replay_draws_fresh_placements():
+    """Under hipGraph capture the reset epoch lives on the device: two replays of a captured hier_step sequence
+    equal the same launches issued eagerly."""
+    N, T, seed = 4096, 24, 3
+    eager = PKG.LmazeFovealVecEnv(N, variant="v5", seed=seed)
+    cap = PKG.LmazeFovealVecEnv(N, variant="v5", seed=seed)
+    for e in (eager, cap):
+        e.foveal_done.fill_(True)
+    gen = torch.Generator(device="cuda").manual_seed(9)
+    acts = torch.randint(0, 4, (T, N), dtype=torch.int32, device="cuda", generator=gen)
+    goals = torch.randint(0, 25, (T, N), dtype=torch.int32, device="cuda", generator=gen)
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    graph = torch.cuda.CUDAGraph()
+    snap = (cap._state.clone(), cap.visit.clone())
+    with torch.cuda.stream(side):
+        with torch.cuda.graph(graph, stream=side):
+            for t in range(T):
+                cap.hier_step_raw(acts[t].data_ptr(), goals[t].data_ptr(), epoch_slot=t)
+    torch.cuda.current_stream().wait_stream(side)
+    cap._state.copy_(snap[0]); cap.visit.copy_(snap[1])      # capture does not run; make sure nothing moved
+    for rep in range(2):
+        cap.begin_replay(T)
+        graph.replay()
+        for t in range(T):
+            eager.hier_step_raw(acts[t].data_ptr(), goals[t].data_ptr())
+        torch.cuda.synchronize()
+        he, hc = eager.host_state(), cap.host_state()
+        for k in he:
+            assert (he[k].view(np.uint8) == hc[k].view(np.uint8)).all(), (k, rep)
+        assert (_bits(_np(eager.visit)) == _bits(_np(cap.visit))).all() and (_bits(_np(eager.obs)) == _bits(_np(cap.obs))).all()
+    assert int(eager.done.sum().item()) >= 0 and eager._epoch == cap._epoch
+
+
+@pytest.mark.parametrize("variant", ["v1", "v2", "v4", "v5"])
+def test_foveal_launch_hint_never_changes_results(variant):
+    """LmazeFovealParams.launch_hint (envs per workgroup, workgroups per CU) is a performance knob only."""
+    N, T = 2500, 12
+    hints = [0] + [(epb << 4) | cu for epb in (2, 3, 4, 5) for cu in (0, 2, 5)] + [0x13, 0x60]   # incl. unsupported codes
+    envs = []
+    for h in hints:
+        e = PKG.LmazeFovealVecEnv(N, variant=variant, seed=5)
+        e.params.launch_hint = h
+        envs.append(e)
+    rs = np.random.RandomState(2)
+    hi = 4 if variant in ("v1", "v5") else 25
+    if variant == "v1":
+        ij = rs.randint(0, 5, (N, 2)).astype(np.int32)
+        for e in envs:
+            e.set_foveal_goal(ij)
+    if variant == "v5":
+        g = rs.randint(0, 25, N).astype(np.int32)
+        for e in envs:
+            e.planner_step(g)
+    for t in range(T):
+        a = torch.from_numpy(rs.randint(0, hi, N).astype(np.int32))
+        for e in envs:
+            e.step(a)
+    ref = envs[0]
+    h0 = ref.host_state()
+    for e in envs[1:]:
+        h = e.host_state()
+        for k in h0:
+            assert (h[k].view(np.uint8) == h0[k].view(np.uint8)).all(), (k, e.params.launch_hint)
+        assert (_bits(_np(e.obs)) == _bits(_np(ref.obs))).all(), e.params.launch_hint
+        if e.visit is not None:
+            assert (_bits(_np(e.visit)) == _bits(_np(ref.visit))).all()
+        if e.obs_local is not None:
+            assert (_bits(_np(e.obs_local)) == _bits(_np(ref.obs_local))).all()
+
+
+def test_foveal_bad_launch_hint_is_refused():
+    e = PKG.LmazeFovealVecEnv(8, variant="v2", seed=1)
+    e.params.launch_hint = 0x100
+    with pytest.raises(PKG._abi.LmazeError):
+        e.step(torch.zeros(8, dtype=torch.int32))

@@ -425,10 +425,11 @@ def test_online_tuner_picks_a_policy_without_changing_results():
     launches the tuner has chosen and stepped aside."""
     N, G = 1 << 19, 11                     # 254 MB of obs: the streaming regime
     lay = L.to_codes(L.open_room(G, (5, 5)))
-    tuned = PKG.LmazeVecEnv(N, variant="v0", layout=lay, seed=6)
-    fixed = PKG.LmazeVecEnv(N, variant="v0", layout=lay, seed=6, online_autotune=False)
-    small = PKG.LmazeVecEnv(4096, variant="v0", layout=lay, seed=6)
+    tuned = PKG.LmazeVecEnv(N, variant="v0", layout=lay, seed=6, online_autotune=True)
+    fixed = PKG.LmazeVecEnv(N, variant="v0", layout=lay, seed=6)          # opt-in: off unless asked for
+    small = PKG.LmazeVecEnv(4096, variant="v0", layout=lay, seed=6, online_autotune=True)
     assert tuned._tuner is not None and fixed._tuner is None and small._tuner is None
+    assert tuned.tuning_progress() == (0, 12 * len(tuned.CANDIDATES)) and fixed.tuning_progress() is None
     acts = torch.randint(0, 4, (8, N), dtype=torch.int32, device="cuda")
     need = tuned._tuner.warm + tuned._tuner.samples * len(tuned.CANDIDATES) + 64
     for t in range(need):

@@ -22,6 +22,7 @@ HOT = {   # mangled-name fragment -> minimum waves per SIMD
     "foveal_kernelILi2ELi0ELi128ELi18ELb0E": 6,            # v2 step
     "foveal_kernelILi4ELi0ELi64ELi18ELb0E": 6,             # v4 step
     "foveal_kernelILi4ELi0ELi64ELi18ELb1E": 6,             # v4 step with the reset fused in
+    "foveal_kernelILi5ELi0ELi64ELi18ELb1E": 5,             # v5/v6 two-level step (reset + plannerStep + step)
     "render_expanded_stream_kernelILi11ELi7ELb1E": 8,
     "render_planes_stream_kernelILb1E": 8,
 }

@@ -189,3 +189,51 @@ def test_oracle_v56_matches_reference(name):
         if ev in (1, 2):
             assert (st.obs_local[0].view(np.uint32) == g["loc_planes"][t].view(np.uint32)).all(), t
             assert obs_hash(O.expand_planes(st.obs_local, E)[0]) == g["loc_hash"][t], t
+
+
+# ---------------------------------------------------------------------------------------
+# the NumPy-vectorised restatement (oracle/oracle_numpy.py, a cpu_baseline leg of bench.py)
+# ---------------------------------------------------------------------------------------
+@pytest.mark.parametrize("name", golden_files("v0_"))
+def test_numpy_v0_matches_reference(name):
+    import oracle_numpy as ON
+    g = load_golden(name)
+    layout = np.ascontiguousarray(g["layout"])
+    G = layout.shape[0]
+    static = ON.static_bits(layout)
+    ball = np.zeros((1, 2), np.int32)
+    sc, gc = np.zeros(1, np.int32), np.zeros(1, np.int32)
+    rew, done = np.zeros(1, np.float32), np.zeros(1, np.uint8)
+    obs = np.zeros((1, G, G), np.int32)
+    for t in range(len(g["actions"])):
+        if g["reset_before"][t]:
+            ball[0] = g["ball_before"][t]
+            sc[0] = 0
+            rew[0] = -0.0
+        ON.step_v0(layout, static, g["actions"][t:t + 1].astype(np.int32), ball, sc, rew, done, gc, obs)
+        assert f32_bits(rew)[0] == ref_reward_bits(g["reward"][t]), t
+        assert done[0] == g["done"][t] and tuple(ball[0]) == tuple(g["ball"][t]) and sc[0] == g["step_count"][t], t
+        assert gc[0] == g["goal_count"][t], t
+        assert (compact_to_ref_bits(obs[0], V0_CHANNEL_MASK) == g["planes"][t]).all(), t
+
+
+@pytest.mark.parametrize("per_env", [False, True])
+def test_numpy_v0_matches_c_oracle_batched(per_env):
+    import oracle_numpy as ON
+    from helpers import bordered_random_layouts, random_free_cells
+    rs = np.random.RandomState(11)
+    n, G = 3000, 11
+    lays = bordered_random_layouts(n if per_env else 1, G, 5)
+    lay = lays if per_env else lays[0]
+    p = O.params(O.VARIANT_V0, G, O.LAYOUT_PER_ENV if per_env else O.LAYOUT_SHARED)
+    ball = random_free_cells(lays if per_env else np.repeat(lays, n, 0), 6)
+    st = [dict(ball=ball.copy(), sc=np.zeros(n, np.int32), rew=np.zeros(n, np.float32), done=np.zeros(n, np.uint8),
+               gc=np.zeros(n, np.int32), obs=np.zeros((n, G, G), np.int32)) for _ in range(2)]
+    static = ON.static_bits(lay)
+    for t in range(150):
+        a = rs.randint(-1, 6, n).astype(np.int32)
+        O.step_v0(p, np.ascontiguousarray(lay), a, st[0]["ball"], st[0]["sc"], st[0]["rew"], st[0]["done"], st[0]["gc"], st[0]["obs"])
+        ON.step_v0(lay, static, a, st[1]["ball"], st[1]["sc"], st[1]["rew"], st[1]["done"], st[1]["gc"], st[1]["obs"])
+        for k in ("ball", "sc", "done", "gc", "obs"):
+            assert (st[0][k] == st[1][k]).all(), (t, k)
+        assert (f32_bits(st[0]["rew"]) == f32_bits(st[1]["rew"])).all(), t
