@@ -43,16 +43,16 @@ def bytes_per_env_step(G, per_env_layout=False):
 
 
 def _timed_loop(fn, budget_s, cap=20000):
-    """Run fn(t) for about budget_s seconds (one call times the pace first); returns (calls, seconds)."""
+    """Call fn(t) until about budget_s seconds have gone by (after one untimed warm-up call); returns (calls, seconds)."""
     fn(0)                                              # warm-up / page-in
     t0 = time.perf_counter()
-    fn(1)
-    one = max(time.perf_counter() - t0, 1e-6)
-    steps = int(max(3, min(cap, budget_s / one)))
-    t0 = time.perf_counter()
-    for t in range(steps):
-        fn(t)
-    return steps, time.perf_counter() - t0
+    steps = 0
+    while True:
+        fn(steps)
+        steps += 1
+        dt = time.perf_counter() - t0
+        if (dt >= budget_s and steps >= 3) or steps >= cap:
+            return steps, dt
 
 
 def host_threads():

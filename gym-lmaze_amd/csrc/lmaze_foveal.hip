@@ -206,8 +206,15 @@ __global__ __launch_bounds__(LMAZE_BLOCK) void foveal_kernel(const FovealArgs a)
             else warmed += warm_lines(a.b.goal_xy, a.n * 8, 256) + warm_lines(a.b.layout_id, a.n * 4, 256);
         }
     }
+#ifdef LMAZE_EXPERIMENT   // timing decomposition only (tools/, never shipped): bit 8 no set-up, 10 no stores, 11 no phase 1
+    const int xp = a.p.launch_hint >> 8;
+    if (!(xp & 1))
+#endif
     for (int i = tid; i < L * CELLS; i += LMAZE_BLOCK) lays[i] = a.layouts[i];
     __syncthreads();
+#ifdef LMAZE_EXPERIMENT
+    if (!(xp & 1))
+#endif
     for (int i = tid; i < L * G; i += LMAZE_BLOCK) {
         uint64_t fr = 0, wl = 0, xx = 0;
         for (int y = 0; y < G; ++y) {
@@ -230,6 +237,9 @@ __global__ __launch_bounds__(LMAZE_BLOCK) void foveal_kernel(const FovealArgs a)
     __syncthreads();
 
     // ---------------- phase 1: one lane per env ----------------
+#ifdef LMAZE_EXPERIMENT
+    if (!(xp & 8))
+#endif
     for (int le = tid; le < nb; le += LMAZE_BLOCK) {
         const int64_t e = blockbase + le;
         EnvRec r;
@@ -552,6 +562,9 @@ __global__ __launch_bounds__(LMAZE_BLOCK) void foveal_kernel(const FovealArgs a)
     // Envs whose map changes are streamed through (load, + window, halve, store; 16-byte accesses) and
     // the cells that fall in their two observation windows are kept in LDS on the way; envs whose map
     // does not change (v5/v6 without localDone) only have those 2 x 25 cells gathered.
+#ifdef LMAZE_EXPERIMENT
+    if (!(xp & 32))
+#endif
     if (V4 && !(V5 && MODE == FM_PLANNER)) {
         float* vis = a.b.visit + (size_t)blockbase * CELLS;
         const int total = nb * CELLS;
@@ -646,6 +659,24 @@ __global__ __launch_bounds__(LMAZE_BLOCK) void foveal_kernel(const FovealArgs a)
     float* obs = a.b.obs + (size_t)blockbase * PERENV;
     const int R = (V5 && MODE == FM_PLANNER) ? 0 : nb * PERENV;   // plannerStep returns only the local observation
     const int nq = some_skipped ? 0 : (R >> 2);
+#ifdef LMAZE_EXPERIMENT
+    if ((xp & 16) && !V4 && EPB == 128) {
+        // timing only: the 4-KiB pieces of 8 consecutive workgroups interleaved (piece k*8 + w of the group's
+        // 1024 envs), content from this workgroup's own bit string (garbage addresses-wise)
+        const int w = blockIdx.x & 7;
+        float* gbase = a.b.obs + (size_t)(blockIdx.x >> 3) * 1024 * PERENV;
+        const int npieces = 1024 * PERENV / 1024;
+        for (int k = 0; k * 8 + w < npieces; ++k) {
+            float v[4];
+            nibble_floats(obits, (k * 256 + tid) % (EPB * PERENV / 4), v);
+            typedef float v4f __attribute__((ext_vector_type(4)));
+            v4f t = {v[0], v[1], v[2], v[3]};
+            v4f* dst = reinterpret_cast<v4f*>(gbase) + (size_t)(k * 8 + w) * 256 + tid;
+            if (a.nt) __builtin_nontemporal_store(t, dst); else *dst = t;
+        }
+    } else
+    if (!(xp & 4))
+#endif
     for (int q = tid; q < nq; q += LMAZE_BLOCK) {
         const int f = q << 2;
         int le = f / PERENV;
@@ -679,6 +710,9 @@ __global__ __launch_bounds__(LMAZE_BLOCK) void foveal_kernel(const FovealArgs a)
     }
 
     // ---------------- phase 3b (v5/v6): the local observation float[nb*4*25], v5:356-380 ----------------
+#ifdef LMAZE_EXPERIMENT
+    if (!(xp & 4))
+#endif
     if (V5 && MODE != FM_RESET) {
         constexpr int PERLOC = 4 * W25;
         float* loc = a.b.obs_local + (size_t)blockbase * PERLOC;
@@ -854,6 +888,9 @@ static hipError_t launch_foveal_one(const FovealArgs& a, hipStream_t s) {
     FovealArgs b = a;
     const int C = VARIANT == LMAZE_VARIANT_V1 ? 4 : (VARIANT == LMAZE_VARIANT_V2 ? 5 : 7);
     b.nt = (size_t)a.n * C * W25 * 4 > ((size_t)192 << 20);
+#ifdef LMAZE_EXPERIMENT
+    if ((a.p.launch_hint >> 8) & 2) b.nt = 0;      // bit 9: plain stores
+#endif
     // launch_hint bits 0-3: at most that many workgroups resident per CU, by padding the dynamic LDS (160 KiB per
     // CU), as the step kernel does in its streaming regime (lmaze_step.hip launch_shared); 0 = no cap
     const int per_cu = a.p.launch_hint & 15;
@@ -902,13 +939,22 @@ static hipError_t launch_foveal_mode(const FovealArgs& a, hipStream_t s) {
             default: if (launch_step_hinted<LMAZE_VARIANT_V5>(a, s, rc)) return rc; break;
         }
     }
+    // Defaults, measured at 1M envs with a fresh action row per step (tools/foveal_hint_study.py, tools/foveal_decompose.py;
+    // us per step, envs per workgroup 32 / 64 / 128 / 256, round 2, after the render went to bit strings):
+    //   v1 (400 B of observation per env)  83 / 78-79 / 84 / 87;  64 envs at 5 workgroups per CU: 73.6-73.7 on three boxes
+    //   v2 (500 B)                        119 / 94-96 / 98-104 / 100-106; the cap is flat or worse
+    // The bare store loop of these kernels (no set-up, no phase 1) takes 88-93 us on v2 and 72-77 us on v1 whatever
+    // the chunk size and the cap: the kernels sit within 3-5 % of what their write pattern -- every workgroup streaming
+    // a private, env-aligned chunk -- reaches on this memory system (tools/wbench.hip: 6.1 TB/s for 32-KiB private
+    // chunks against 6.9 for a fill in which consecutive workgroups write consecutive 4-KiB pieces).
+    FovealArgs h = a;
+    if (MODE == FM_STEP && a.p.variant == LMAZE_VARIANT_V1 && (a.p.launch_hint & 15) == 0 && !a.auto_reset)
+        h.p.launch_hint |= 5;
     switch (a.p.variant) {
-        // envs per workgroup, measured warm at 1M envs (TB/s of algorithmic traffic, 256 / 128 / 64 envs):
-        //   v1 (400 B of observation per env)  5.9-6.0 / 6.1 / 6.7-6.8      v2 (500 B)  5.9 / 6.1 / 5.8
-        case LMAZE_VARIANT_V1: return launch_foveal_one<LMAZE_VARIANT_V1, MODE, 64>(a, s);
+        case LMAZE_VARIANT_V1: return launch_foveal_one<LMAZE_VARIANT_V1, MODE, 64>(h, s);
         case LMAZE_VARIANT_V2:
             if (MODE == FM_STEP && a.auto_reset) return launch_foveal_one<LMAZE_VARIANT_V2, MODE, 256>(a, s);
-            return launch_foveal_one<LMAZE_VARIANT_V2, MODE, 128>(a, s);
+            return launch_foveal_one<LMAZE_VARIANT_V2, MODE, 64>(a, s);
         case LMAZE_VARIANT_V5:
         case LMAZE_VARIANT_V6:
             return launch_foveal_one<LMAZE_VARIANT_V5, MODE, 64>(a, s);
@@ -926,7 +972,9 @@ static int check_foveal(const LmazeFovealParams* p, const uint8_t* layouts, cons
     if (p->grid < FOV || p->grid > LMAZE_MAX_GRID) return LMAZE_E_GRID;
     if (p->n_layouts < 1 || p->n_layouts > LMAZE_MAX_LAYOUTS) return LMAZE_E_LAYOUT;
     if (n < 0 || n > LMAZE_MAX_ENVS) return LMAZE_E_COUNT;
+#ifndef LMAZE_EXPERIMENT
     if (p->launch_hint & ~0xff) return LMAZE_E_LAYOUT;
+#endif
     if (v56) {
         if (!b->fgoal_xy || !b->foveal_step_count || !b->foveal_reward || !b->foveal_done || !b->visit || !b->ball1_xy ||
             !b->fovea_xy || !b->last_xy || !b->foveal_goal || !b->obs_local)

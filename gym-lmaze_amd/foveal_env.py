@@ -48,7 +48,6 @@ class LmazeFovealVecEnv(object):
         self.channels = spec["channels"]
         self.expansion = spec["expansion"]
         self.seed, self.env_base, self._epoch = int(seed), int(env_base), 0
-        self._epoch_words = None     # device-resident epoch pair (captured auto-reset steps)
         tabs = [L.to_codes(t) for t in (layouts if layouts is not None else spec["layouts"])]
         G = tabs[0].shape[0]
         pad = 2 if variant == "v1" else 2   # the 5x5 window must stay inside the array
@@ -74,6 +73,9 @@ class LmazeFovealVecEnv(object):
             offs[name] = total
             total += _align(sz)
         self._state = torch.zeros(total, dtype=torch.uint8, device=self.device)
+        # device-resident epoch pair of captured auto-reset / two-level steps; allocated here, never under capture
+        # (an allocation inside a capture becomes a memset node that every replay would re-run)
+        self._epoch_words = torch.zeros(2, dtype=torch.int64, device=self.device)
 
         def view(name, nbytes, dtype, shape):
             return self._state[offs[name]:offs[name] + nbytes].view(dtype).view(shape)
@@ -155,8 +157,6 @@ class LmazeFovealVecEnv(object):
     def begin_replay(self, n_launches):
         """Before replaying a captured sequence of n_launches auto-reset steps (step(..., epoch_slot=t)):
         hand the host's epoch count to the device word launch 0 reads and reserve n_launches epochs."""
-        if self._epoch_words is None:
-            self._epoch_words = torch.zeros(2, dtype=torch.int64, device=self.device)
         self._epoch_words[0:1].fill_(self._epoch)
         self._epoch += int(n_launches)
 
@@ -176,8 +176,6 @@ class LmazeFovealVecEnv(object):
                     epoch, e_in, e_out = self._epoch, None, None
                     self._epoch += 1
                 else:
-                    if self._epoch_words is None:
-                        self._epoch_words = torch.zeros(2, dtype=torch.int64, device=self.device)
                     base, t = self._epoch_words.data_ptr(), int(epoch_slot)
                     epoch, e_in, e_out = 0, base + 8 * (t & 1), base + 8 * ((t + 1) & 1)
                 rc = _abi.lib.lmaze_foveal_step_autoreset(self._pp, self._p_layouts, a.data_ptr(), self._pb,
@@ -222,8 +220,6 @@ class LmazeFovealVecEnv(object):
                 epoch, e_in, e_out = self._epoch, None, None
                 self._epoch += 1
             else:
-                if self._epoch_words is None:
-                    self._epoch_words = torch.zeros(2, dtype=torch.int64, device=self.device)
                 base, t = self._epoch_words.data_ptr(), int(epoch_slot)
                 epoch, e_in, e_out = 0, base + 8 * (t & 1), base + 8 * ((t + 1) & 1)
             rc = _abi.lib.lmaze_v5_hier_step(self._pp, self._p_layouts, action_ptr, goal_ptr, self._pb, self.num_envs,

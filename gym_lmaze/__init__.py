@@ -12,9 +12,14 @@ import os
 import sys
 
 _root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-if _root not in sys.path:
-    sys.path.insert(0, _root)
-_impl = importlib.import_module("gym-lmaze_amd")
+if os.path.isdir(os.path.join(_root, "gym-lmaze_amd")):
+    # a checkout: the implementation sits next to this package under its hyphenated directory name
+    if _root not in sys.path:
+        sys.path.insert(0, _root)
+    _impl = importlib.import_module("gym-lmaze_amd")
+else:
+    # `pip install .` (setup.py): the same package under the import name gym_lmaze_amd
+    _impl = importlib.import_module("gym_lmaze_amd")
 
 make = _impl.make
 registered_ids = _impl.registered_ids

@@ -1,7 +1,5 @@
 """Entry-point module of the registered ids (reference: gym_lmaze/envs/__init__.py)."""
-import importlib
-
-_impl = importlib.import_module("gym-lmaze_amd")
+from .. import _impl
 LmazeEnv = _impl.LmazeEnv
 LmazeEnv_v3 = _impl.LmazeEnv_v3
 LmazeEnv_v1 = _impl.LmazeEnv_v1

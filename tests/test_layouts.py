@@ -69,3 +69,28 @@ def test_shard_range_partitions():
             assert max(c for _, c in spans) - min(c for _, c in spans) <= 1
     with pytest.raises(ValueError):
         S.shard_range(10, 2, 2)
+
+
+def test_setup_py_installs_alias_package_implementation_and_library(tmp_path):
+    """The reference installs with `pip install -e .` (its setup.py:1-6).  Ours: setup.py builds liblmaze_hip.so and
+    installs `gym_lmaze` + the implementation (import name gym_lmaze_amd) with the .so as package data; the
+    installed copy imports from anywhere and registers the ids."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    prefix = tmp_path / "p"
+    subprocess.run([sys.executable, "setup.py", "-q", "build", "--build-base", str(tmp_path / "b"), "install", "--prefix",
+                    str(prefix), "--single-version-externally-managed", "--record", str(tmp_path / "rec.txt")],
+                   cwd=root, check=True, capture_output=True, timeout=900)
+    site = [os.path.join(b, "site-packages") for b, d, _ in os.walk(str(prefix)) if "site-packages" in d][0]
+    assert os.path.exists(os.path.join(site, "gym_lmaze_amd", "liblmaze_hip.so"))
+    code = ("import gym_lmaze, gym_lmaze.envs as E; assert gym_lmaze._impl.__name__ == 'gym_lmaze_amd'; "
+            "assert gym_lmaze.registered_ids() == ['lmaze-v%d' % k for k in range(7)]; "
+            "assert E.LmazeEnv.__module__.startswith('gym_lmaze_amd'); print('ok')")
+    out = subprocess.run([sys.executable, "-c", code], cwd=str(tmp_path), env=dict(os.environ, PYTHONPATH=site),
+                         capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0 and out.stdout.strip() == "ok", out.stderr[-2000:]
+    for junk in ("build", "gym_lmaze.egg-info"):
+        import shutil
+        shutil.rmtree(os.path.join(root, junk), ignore_errors=True)
