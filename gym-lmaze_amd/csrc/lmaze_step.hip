@@ -523,6 +523,116 @@ __global__ __launch_bounds__(LMAZE_BLOCK) void step_perenv_wave_kernel(const Ste
 }
 
 // ------------------------------------------------------------------------------------
+// Shared 8x8 layout, small batches (BASELINE config 2: 65 536 x 8x8, 16.8 MB of planes): wave-autonomous.
+// At this size a launch is nothing but a latency chain -- 5.7-6.0 us per step against 4.6 us for a bare fill
+// of the same bytes -- so the chain is cut to its minimum: no LDS, no workgroup barrier.  One wave = 64 envs;
+// lane l holds the layout byte of cell l (the 64 cells ARE the wave), so the transition's target cell and the
+// render's pattern come from other lanes by ds_bpermute; the wave's 64 x 256 B of planes are one contiguous
+// 16 KiB, 16 stores per lane, store k of lane l covering cells 4(l % 16)..+3 of env l/16 + 4k -- the pattern
+// int4 is loop-invariant per lane.  Fused auto-reset: the accepted spawn cells are a 64-bit ballot.
+// ------------------------------------------------------------------------------------
+__device__ __forceinline__ int kth_set_bit(unsigned long long m, int k) {   // position of the k-th (0-based) set bit
+    int pos = 0;
+#pragma unroll
+    for (int sh = 32; sh > 0; sh >>= 1) {
+        const unsigned long long low = m & ((1ull << sh) - 1ull);
+        const int c = __popcll(low);
+        if (k >= c) { k -= c; m >>= sh; pos += sh; } else { m = low; }
+    }
+    return pos;
+}
+
+// EPW = envs per wave (64, 32 or 16: fewer envs per wave = more, shorter waves to hide the load latency with)
+// Tried and dropped (round 2): storing the ball-free planes first -- they need the 64-byte layout only -- and
+// patching the ball cell's dword once the inputs have arrived, to hide the load latency behind the stores: 6.5-7.7 us
+// instead of 5.6 (one partial-line store per env costs more than the latency it hides).
+template <int VARIANT, bool DO_STEP, int EPW>
+__global__ __launch_bounds__(64) void step_shared_wave8_kernel(const StepArgs a) {
+    constexpr bool V3 = VARIANT == LMAZE_VARIANT_V3;
+    constexpr int G = 8, CELLS = 64;
+    const int lane = threadIdx.x;
+    const int64_t base = (int64_t)blockIdx.x * EPW;
+    const int nb = (int)min((int64_t)EPW, a.n - base);
+    const bool autoreset = DO_STEP && a.auto_reset;
+    if (autoreset) pass_epoch_on(a.epoch_in, a.epoch_out);
+    const bool live = lane < nb;
+    EnvIn in{};
+    in.b = make_int2(1, 1); in.g = make_int2(-1, -1);
+    if (live) in = load_env<VARIANT, DO_STEP>(a, base + lane);
+    const int myc = a.layout[lane];                                   // cell `lane` of the layout
+    const int mypat = cell_bits<VARIANT>((uint8_t)myc);
+    const int p4 = (lane & 15) << 2;                                  // first cell of this lane's stores
+    const int4 pat4 = make_int4(__shfl(mypat, p4, 64), __shfl(mypat, p4 + 1, 64), __shfl(mypat, p4 + 2, 64),
+                                __shfl(mypat, p4 + 3, 64));
+    int4* obs4 = reinterpret_cast<int4*>(a.obs + (size_t)base * CELLS);
+    int2 b = in.b, g = in.g;
+    if (DO_STEP) {
+        int sc_in = in.sc;
+        float r_in = in.r;
+        if (autoreset) {   // reference reset(): placement over the accepted cells, ranked row-major (lmaze_common.h place_from_list)
+            const unsigned long long ok = __ballot(interior(lane, G) && spawn_ok<VARIANT>((uint8_t)myc));
+            if (in.was_done) {
+                const uint4 d = env_draw(a.seed, launch_epoch(a.epoch, a.epoch_in), a.env_base + base + lane);
+                const int count = __popcll(ok);
+                if (V3) {
+                    int kg = -1;
+                    if (count > 0) {
+                        kg = (int)__umulhi(d.x, (uint32_t)count);
+                        const int gc = kth_set_bit(ok, kg);
+                        g = make_int2(gc / G, gc % G);
+                        if (live) a.goal_rw[base + lane] = g;
+                    }
+                    if (count > 1) {
+                        int kb = (int)__umulhi(d.y, (uint32_t)(count - 1));
+                        kb += (kb >= kg);
+                        const int bc = kth_set_bit(ok, kb);
+                        b = make_int2(bc / G, bc % G);
+                    }
+                } else if (count > 0) {
+                    const int bc = kth_set_bit(ok, (int)__umulhi(d.y, (uint32_t)count));
+                    b = make_int2(bc / G, bc % G);
+                }
+                sc_in = 0;      // v0:110
+                r_in = -0.0f;   // v0:109
+            }
+        }
+        int bx = clampi(b.x, 0, G - 1), by = clampi(b.y, 0, G - 1);
+        const int sc = sc_in + 1;  // v0:151, v3:225
+        int ox, oy;
+        decode_action(in.act, ox, oy);
+        const int tx = clampi(bx + ox, 0, G - 1), ty = clampi(by + oy, 0, G - 1);
+        const uint8_t c = (uint8_t)__shfl(myc, tx * G + ty, 64);      // v0:172, v3:251 -- every lane takes part
+        float r;
+        bool dn;
+        const bool hit = transition_rule<VARIANT>(a, c, ox, oy, tx, ty, sc, r_in, g.x, g.y, bx, by, r, dn);
+        if (live) {
+            const int64_t e = base + lane;
+            if (hit && a.goal_count) a.goal_count[e] += 1;
+            a.ball[e] = make_int2(bx, by);
+            a.step_count[e] = sc;
+            a.reward[e] = r;
+            a.done[e] = dn ? 1 : 0;
+        }
+        b = make_int2(bx, by);
+    } else {
+        b = make_int2(clampi(b.x, 0, G - 1), clampi(b.y, 0, G - 1));
+    }
+    if (a.obs == nullptr) return;
+    const int ball_cell = b.x * G + b.y;
+    const int goal_cell = (V3 && g.x >= 0 && g.x < G && g.y >= 0 && g.y < G) ? g.x * G + g.y : -8;
+#pragma unroll
+    for (int k = 0; k < EPW / 4; ++k) {
+        const int le = (lane >> 4) + 4 * k;                           // env of store k
+        const int bc = __shfl(ball_cell, le, 64);
+        const int gc = V3 ? __shfl(goal_cell, le, 64) : -8;
+        int4 v = pat4;
+        or_at(v, bc - p4, LMAZE_OBS_BALL);
+        if (V3) or_at(v, gc - p4, LMAZE_OBS_GOAL);
+        if (le < nb) obs4[lane + 64 * k] = v;
+    }
+}
+
+// ------------------------------------------------------------------------------------
 // host launchers
 // ------------------------------------------------------------------------------------
 // Obs buffers larger than this are written with non-temporal stores: they cannot stay in the
@@ -644,6 +754,21 @@ static hipError_t launch_one(const StepArgs& a, int layout_mode, hipStream_t s) 
     if (a.n == 0) return hipSuccess;
     if (layout_mode != LMAZE_LAYOUT_SHARED) return launch_perenv<GT, VARIANT, DO_STEP>(a, s);
     if constexpr (GT == 8) {
+        // small batches (the planes stay on-die): the wave-autonomous kernel, no LDS, no barrier
+        const bool small = a.obs == nullptr || (size_t)a.n * 64 * 4 <= kNonTemporalObsBytes;
+        if (small && a.mask == nullptr && (a.launch_hint & 0x100) == 0) {
+            // envs per wave: launch_hint bits 4-7 = 1: 64, 2: 32, 3: 16 (0 = default)
+            int code = (a.launch_hint >> 4) & 15;
+            if (code < 1 || code > 3) code = 2;
+            const int epw = 128 >> code;
+            const int64_t blocks = (a.n + epw - 1) / epw;
+            if (!grid_ok(blocks)) return hipErrorInvalidConfiguration;
+            const dim3 grid((unsigned)blocks), block(64);
+            if (code == 1) hipLaunchKernelGGL((step_shared_wave8_kernel<VARIANT, DO_STEP, 64>), grid, block, 0, s, a);
+            else if (code == 2) hipLaunchKernelGGL((step_shared_wave8_kernel<VARIANT, DO_STEP, 32>), grid, block, 0, s, a);
+            else hipLaunchKernelGGL((step_shared_wave8_kernel<VARIANT, DO_STEP, 16>), grid, block, 0, s, a);
+            return hipGetLastError();
+        }
         return launch_shared<GT, VARIANT, DO_STEP, 128>(a, s);
     } else if constexpr (GT == 11 || GT == 12) {
         return launch_shared<GT, VARIANT, DO_STEP, 64>(a, s);

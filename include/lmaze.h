@@ -80,7 +80,10 @@ typedef struct LmazeParams {
     int32_t launch_hint; /* 0 = library default launch policy; else bits 0-3 = workgroups per
                             CU (1..8, 0 = default), bits 4-7 = chunks of envs a workgroup
                             takes one after the other, loading the next chunk's inputs while
-                            it stores the current one (1..15, 0 = default).  Performance only,
+                            it stores the current one (1..15, 0 = default); bit 8 = keep the
+                            workgroup/LDS kernel where the library would pick the wave-autonomous
+                            one (8x8 shared layouts whose planes stay on-die); for that kernel
+                            bits 4-7 = envs per wave (1: 64, 2: 32, 3: 16).  Performance only,
                             never results (lmaze_step.hip launch_shared); other bits 0.      */
 } LmazeParams;
 

@@ -346,7 +346,7 @@ def test_reset_placement_is_uniform_over_accepted_cells():
 # 4b. fused auto-reset == reset(mask=done) then step, bit for bit (incl. the Philox epochs)
 # ----------------------------------------------------------------------------------------
 @pytest.mark.parametrize("variant", ["v0", "v3"])
-@pytest.mark.parametrize("shared,G", [(True, 11), (True, 12), (True, 9), (False, 8), (False, 11), (False, 32), (False, 16)])
+@pytest.mark.parametrize("shared,G", [(True, 8), (True, 11), (True, 12), (True, 9), (False, 8), (False, 11), (False, 32), (False, 16)])
 def test_fused_autoreset_equals_reset_then_step(variant, shared, G):
     N, T, seed = 2500, 60, 21
     kw = dict(variant=variant, seed=seed, step_limit=7, env_base=1000)   # short episodes: many resets
@@ -553,3 +553,49 @@ def test_fused_autoreset_fuzz():
         shared = bool(rs.rand() < 0.5)
         G = int(rs.randint(5, 41))
         test_fused_autoreset_equals_reset_then_step(variant, shared, G)
+
+
+# ----------------------------------------------------------------------------------------
+# 8. the wave-autonomous 8x8 kernel (small shared-layout batches, BASELINE config 2) against the workgroup/LDS
+#    kernel it replaces there (LmazeParams.launch_hint bit 8 keeps the latter) and against the oracle
+# ----------------------------------------------------------------------------------------
+@pytest.mark.parametrize("variant", ["v0", "v3"])
+@pytest.mark.parametrize("N,hint", [(1, 0), (63, 0x10), (64, 0x10), (65, 0x20), (130, 0x30), (3003, 0), (3003, 0x10), (3003, 0x30)])
+def test_wave_autonomous_8x8_kernel_equals_the_lds_kernel_and_the_oracle(variant, N, hint):
+    lay = bordered_random_layouts(1, 8, 41 + N)[0]
+    kw = dict(variant=variant, layout=lay, seed=5, step_limit=9, env_base=3)
+    wave, lds = PKG.LmazeVecEnv(N, **kw), PKG.LmazeVecEnv(N, **kw)
+    wave.params.launch_hint = hint           # envs per wave: 64 / 32 / 16 (0 = the default)
+    lds.params.launch_hint = 0x100
+    assert (wave.obs == lds.obs).all() and (wave._state == lds._state).all()          # constructor: reset + planes
+    p, st = _oracle_state(wave, variant, lay)
+    obs_ref = np.zeros((N, 8, 8), np.int32)
+    lay_c = np.ascontiguousarray(lay)
+    rs = np.random.RandomState(N)
+    epoch = wave._epoch
+    for t in range(50):
+        a = np.where(rs.rand(N) < 0.85, rs.randint(0, 4, N), rs.randint(-1, 6, N)).astype(np.int32)
+        ta = torch.from_numpy(a)
+        auto = t % 3 != 2                     # fused auto-reset on most steps, plain ones in between
+        render = t % 7 != 6                   # and some transition-only steps (obs = NULL)
+        for e in (wave, lds):
+            e.step(ta, render=render, auto_reset=auto)
+        if auto:
+            O.reset(p, lay_c, st["done"].copy(), 5, epoch, st["ball_xy"], st["goal_xy"] if variant == "v3" else None,
+                    st["step_count"], st["reward"], st["done"], None, env_base=3)
+            epoch += 1
+        if variant == "v3":
+            O.step_v3(p, lay_c, a, st["ball_xy"], st["goal_xy"], st["step_count"], st["reward"], st["done"], obs_ref)
+        else:
+            O.step_v0(p, lay_c, a, st["ball_xy"], st["step_count"], st["reward"], st["done"], st["goal_count"], obs_ref)
+        hw, hl = wave.host_state(), lds.host_state()
+        for k in hw:
+            assert (hw[k].view(np.uint8) == hl[k].view(np.uint8)).all(), (k, t)
+        for k in ("ball_xy", "step_count", "goal_count", "done") + (("goal_xy",) if variant == "v3" else ()):
+            assert (hw[k] == st[k]).all(), (k, t)
+        assert (f32_bits(hw["reward"]) == f32_bits(st["reward"])).all(), t
+        if render:
+            assert (wave.obs == lds.obs).all() and (_np(wave.obs) == obs_ref).all(), t
+        else:
+            assert (_np(wave.observe()) == obs_ref).all() and (_np(lds.observe()) == obs_ref).all(), t
+    assert wave._epoch == lds._epoch == epoch
