@@ -169,9 +169,11 @@ __global__ __launch_bounds__(LMAZE_BLOCK) void foveal_kernel(const FovealArgs a)
     // LDS: per-env plane masks and window centres, the two 5x5 samples of the visit map (v4-v6), one
     // 64-bit row mask per layout row for each static plane, and the layout characters for the transition
     extern __shared__ int4 lds4[];
-    uint32_t* masks = reinterpret_cast<uint32_t*>(lds4);                   // [EPB][8]  25-bit planes of obs
-    uint32_t* lmasks = masks + EPB * 8;                                    // [EPB][4]  planes of obs_local (v5/v6)
-    int16_t* cen = reinterpret_cast<int16_t*>(lmasks + EPB * 4);           // [EPB][4]  cx, cy, px, py
+    // the 0/1 planes as bit strings, bit f = float f of the workgroup's contiguous output range (the float visit
+    // planes of v4-v6 are zero bits there and come from vwin): a 16-byte store is one nibble of the string
+    uint32_t* obits = reinterpret_cast<uint32_t*>(lds4);                   // [EPB*PERENV bits]  obs
+    uint32_t* lbits = obits + EPB * 8;                                     // [EPB*100 bits]     obs_local (v5/v6)
+    int16_t* cen = reinterpret_cast<int16_t*>(lbits + EPB * 4);            // [EPB][4]  cx, cy, px, py
     int32_t* flags = reinterpret_cast<int32_t*>(cen + EPB * 4);            // [EPB]     bit0 skip, bit1 visit update, bit2 fresh episode, bit3 not stepped
     int16_t* rcen = reinterpret_cast<int16_t*>(flags + EPB);               // [EPB][2]  ball a fused reset placed (visit map re-init)
     float* vwin = reinterpret_cast<float*>(rcen + EPB * 2);                // [EPB][2][25] visit-map samples (v4-v6)
@@ -181,18 +183,14 @@ __global__ __launch_bounds__(LMAZE_BLOCK) void foveal_kernel(const FovealArgs a)
     uint64_t* rowwall = rowball + L * G;                                   // [G] v1: 'W'
     uint64_t* rowx = rowwall + G;                                          // [G] v1: 'X'
     uint8_t* lays = reinterpret_cast<uint8_t*>(rowx + G);                  // [L*CELLS]
-    // the 0/1 planes of the workgroup's observations as ONE bit string, bit f = float f of the workgroup's
-    // contiguous output range (v1, v2: obs; v5/v6: obs_local): a 16-byte store is then one nibble of it
-    uint32_t* obits = reinterpret_cast<uint32_t*>(lays + ((L * CELLS + 15) & ~15));   // [BITW]
-    constexpr int BITW = (EPB * (V5 ? 4 * W25 : PERENV) + 31) / 32 + 1;
+    static_assert(PERENV <= 8 * 32 - 32 && 4 * W25 <= 4 * 32 - 4, "bit strings fit the 32 B / 16 B per env reserved for them");
     __shared__ int any_skip;
 
     const int tid = threadIdx.x;
     const int64_t blockbase = (int64_t)blockIdx.x * EPB;
     const int nb = (int)min((int64_t)EPB, a.n - blockbase);
     if (tid == 0) any_skip = 0;
-    if (!V4 || V5)
-        for (int i = tid; i < BITW; i += LMAZE_BLOCK) obits[i] = 0u;
+    for (int i = tid; i < EPB * 12; i += LMAZE_BLOCK) obits[i] = 0u;       // obits and lbits
     if (MODE == FM_STEP && AR) pass_epoch_on(a.epoch_in, a.epoch_out);
     // large batches: the first 256 workgroups touch every 64-byte line of this step's action array at kernel
     // start, one burst of reads, so that the per-workgroup loads later in the launch hit the memory-side cache
@@ -210,11 +208,65 @@ __global__ __launch_bounds__(LMAZE_BLOCK) void foveal_kernel(const FovealArgs a)
     const int xp = a.p.launch_hint >> 8;
     if (!(xp & 1))
 #endif
+    if (GT != 0) {
+        // Row masks by ballot, straight from global memory: a wave-iteration covers RPW whole layout rows (their
+        // characters are RPW*G contiguous bytes, one per lane), four ballots give the rows' masks, and every load of
+        // the workgroup -- these and the copy of the characters the transition looks cells up in -- is in flight
+        // before the first is used.  One barrier.  (Round 1 copied the characters to LDS byte by byte, barrier, then
+        // 90 lanes walked 18 LDS bytes each, twice: 58 of the 520 us of a v5 launch.)
+        constexpr int GG = GT ? GT : 1, RPW = 64 / GG, UNR = 8;
+        const int wave = tid >> 6, lane = tid & 63, rows = L * G;
+        const int rsub = lane / GG, y = lane - rsub * GG;
+        const bool dwords = ((reinterpret_cast<uintptr_t>(a.layouts) | (uintptr_t)(L * CELLS)) & 3) == 0;
+        uint32_t cw[2] = {0u, 0u};
+        if (dwords) {
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+                if (tid + j * LMAZE_BLOCK < (L * CELLS) >> 2) cw[j] = reinterpret_cast<const uint32_t*>(a.layouts)[tid + j * LMAZE_BLOCK];
+        }
+        for (int r00 = 0; r00 < rows; r00 += UNR * 4 * RPW) {
+            uint8_t cc[UNR];
+#pragma unroll
+            for (int u = 0; u < UNR; ++u) {
+                const int row = r00 + (u * 4 + wave) * RPW + rsub;
+                cc[u] = (rsub < RPW && row < rows) ? a.layouts[(size_t)row * G + y] : (uint8_t)0;
+            }
+#pragma unroll
+            for (int u = 0; u < UNR; ++u) {
+                const int row = r00 + (u * 4 + wave) * RPW + rsub;
+                const bool in = rsub < RPW && row < rows;
+                const uint8_t c = cc[u];
+                const unsigned long long bf = __ballot(in && (c == 'B' || c == 'S' || c == 'X'));   // v1:78, v2:94
+                const unsigned long long bw = __ballot(in && c == 'W');                              // v1:70
+                const unsigned long long bx = __ballot(in && c == 'X');                              // v1:74
+                const unsigned long long bs = __ballot(in && c == 'S');
+                if (in && y == 0) {
+                    const int sh = rsub * GG;
+                    const uint64_t keep = GG == 64 ? ~0ull : ((1ull << GG) - 1ull);
+                    const uint64_t fr = (bf >> sh) & keep, wl = (bw >> sh) & keep, xx = (bx >> sh) & keep, ss = (bs >> sh) & keep;
+                    rowfree[row] = fr;
+                    if (V1) { rowwall[row] = wl; rowx[row] = xx; }
+                    if (!V1 && (MODE == FM_RESET || (MODE == FM_STEP && AR))) {
+                        const int x = row % G;
+                        const uint64_t interior = (x >= 1 && x <= G - 2) ? (((1ull << (G - 2)) - 1ull) << 1) : 0ull;
+                        rowgoal[row] = fr & ~ss & interior;      // B or X
+                        rowball[row] = fr & ~xx & interior;      // B or S
+                    }
+                }
+            }
+        }
+        if (dwords) {
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+                if (tid + j * LMAZE_BLOCK < (L * CELLS) >> 2) reinterpret_cast<uint32_t*>(lays)[tid + j * LMAZE_BLOCK] = cw[j];
+            for (int i = tid + 2 * LMAZE_BLOCK; i < (L * CELLS) >> 2; i += LMAZE_BLOCK)     // more than 2 KiB of layouts
+                reinterpret_cast<uint32_t*>(lays)[i] = reinterpret_cast<const uint32_t*>(a.layouts)[i];
+        } else {
+            for (int i = tid; i < L * CELLS; i += LMAZE_BLOCK) lays[i] = a.layouts[i];
+        }
+    } else {
     for (int i = tid; i < L * CELLS; i += LMAZE_BLOCK) lays[i] = a.layouts[i];
     __syncthreads();
-#ifdef LMAZE_EXPERIMENT
-    if (!(xp & 1))
-#endif
     for (int i = tid; i < L * G; i += LMAZE_BLOCK) {
         uint64_t fr = 0, wl = 0, xx = 0;
         for (int y = 0; y < G; ++y) {
@@ -233,6 +285,7 @@ __global__ __launch_bounds__(LMAZE_BLOCK) void foveal_kernel(const FovealArgs a)
             rowgoal[i] = fr & ~ss & interior;      // B or X
             rowball[i] = fr & ~xx & interior;      // B or S
         }
+    }
     }
     __syncthreads();
 
@@ -518,8 +571,7 @@ __global__ __launch_bounds__(LMAZE_BLOCK) void foveal_kernel(const FovealArgs a)
         }
         r.cx = (int16_t)bx; r.cy = (int16_t)by;
         // the observation as 25-bit planes (the float visit planes are sampled in phase 3)
-        uint32_t mreg[8];
-        uint32_t* m = V4 ? masks + le * 8 : mreg;     // v1, v2: straight into the workgroup's bit string below
+        uint32_t m[8];
         if (V1) {
             m[0] = 1u << 12;                                                               // ball, v1:216
             m[1] = window_bits(rowwall, G, r.cx, r.cy);
@@ -543,12 +595,13 @@ __global__ __launch_bounds__(LMAZE_BLOCK) void foveal_kernel(const FovealArgs a)
                 lm[2] = (i1 >= 0 && j1 >= 0) ? (1u << (FOV * i1 + j1)) : 0u;
                 lm[3] = m[PER];
                 if (MODE != FM_RESET && !r.skip)
-                    for (int ch = 0; ch < 4; ++ch) put_bits(obits, le * (4 * W25) + ch * W25, lm[ch]);
+                    for (int ch = 0; ch < 4; ++ch) put_bits(lbits, le * (4 * W25) + ch * W25, lm[ch]);
             }
         }
-        if (!V4 && !r.skip) {
+        if (!r.skip) {
 #pragma unroll
-            for (int ch = 0; ch < C; ++ch) put_bits(obits, le * PERENV + ch * W25, m[ch]);
+            for (int ch = 0; ch < C; ++ch)
+                if (!(V4 && (ch == 2 || ch == 6))) put_bits(obits, le * PERENV + ch * W25, m[ch]);
         }
         cen[le * 4 + 0] = r.cx; cen[le * 4 + 1] = r.cy; cen[le * 4 + 2] = r.px; cen[le * 4 + 3] = r.py;
         flags[le] = (r.skip ? 1 : 0) | (r.upd ? 2 : 0) | (fresh ? 4 : 0) | (nostep ? 8 : 0);
@@ -559,62 +612,92 @@ __global__ __launch_bounds__(LMAZE_BLOCK) void foveal_kernel(const FovealArgs a)
     const bool some_skipped = any_skip != 0;
 
     // ---------------- phase 2 (v4-v6): the visit maps, v4:116-119 / v4:211-214 / v5:313-318 ----------------
-    // Envs whose map changes are streamed through (load, + window, halve, store; 16-byte accesses) and
-    // the cells that fall in their two observation windows are kept in LDS on the way; envs whose map
-    // does not change (v5/v6 without localDone) only have those 2 x 25 cells gathered.
+    // Envs whose map changes are streamed through (load, + window, halve, store; 16-byte accesses); then, after a
+    // barrier, the 2 x 25 cells the two observation windows show are gathered for every env, one lane per window
+    // row -- from the lines the workgroup has just written, or, for maps that do not change (v5/v6 without
+    // localDone), from HBM.  (Round 1 tested every streamed cell against both windows on the way: two thirds of
+    // the stream's 170 VALU instructions per 16 bytes, on the kernel's critical resource.)
 #ifdef LMAZE_EXPERIMENT
     if (!(xp & 32))
 #endif
     if (V4 && !(V5 && MODE == FM_PLANNER)) {
         float* vis = a.b.visit + (size_t)blockbase * CELLS;
         const int total = nb * CELLS;
-        auto keep = [&](int le, int c, float v) {   // c = cell index of env le; stash it if a window shows it
-            const int x = c / G, y = c - x * G;
-            int i = x - cen[le * 4] + 2, j = y - cen[le * 4 + 1] + 2;
-            if (i >= 0 && i < FOV && j >= 0 && j < FOV) vwin[le * 2 * W25 + i * FOV + j] = v;
-            i = x - cen[le * 4 + 2] + 2; j = y - cen[le * 4 + 3] + 2;
-            if (i >= 0 && i < FOV && j >= 0 && j < FOV) vwin[le * 2 * W25 + W25 + i * FOV + j] = v;
+        // (v + w) * 0.5f in float32 == the reference's float64 round trip: the add rounds once, the halving is exact
+        auto update4 = [&](float4& v, int c0, int cx, int cy) {
+            int x = c0 / G, y = c0 - x * G;
+            float* p = &v.x;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const float w = ((unsigned)(x - cx + 2) <= 4u && (unsigned)(y - cy + 2) <= 4u) ? 1.0f : 0.0f;
+                p[k] = (p[k] + w) * 0.5f;
+                if (++y == G) { y = 0; ++x; }
+            }
         };
         auto update = [&](float v, int c, int cx, int cy) -> float {
             const int x = c / G, y = c - x * G;
-            const float w = (x >= cx - 2 && x <= cx + 2 && y >= cy - 2 && y <= cy + 2) ? 1.0f : 0.0f;
-            return (v + w) * 0.5f;  // float32 add + exact halving == the reference's float64 round trip
+            const float w = ((unsigned)(x - cx + 2) <= 4u && (unsigned)(y - cy + 2) <= 4u) ? 1.0f : 0.0f;
+            return (v + w) * 0.5f;
         };
         // window cells outside the array read 0 (the padded layouts never get there)
         for (int i = tid; i < nb * 2 * W25; i += LMAZE_BLOCK) vwin[i] = 0.0f;
-        __syncthreads();
         if ((CELLS & 3) == 0) {  // a 16-byte access never straddles two envs
-            for (int q = tid; q < (total >> 2); q += LMAZE_BLOCK) {
-                const int f0 = q << 2;
-                const int le = f0 / CELLS;
-                const int c0 = f0 - le * CELLS;
-                const int fl = flags[le];
-                const bool skip = fl & 1, upd = fl & 2;
-                const bool fresh = MODE == FM_STEP && AR && (fl & 4), nostep = MODE == FM_STEP && AR && (fl & 8);
-                if (skip || (V5 && MODE == FM_STEP && !upd && !fresh)) continue;   // map unchanged: gathered below
-                const int cx = cen[le * 4], cy = cen[le * 4 + 1];
-                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);                 // reset: v4:112 / v5:130
-                // STEP loads unconditionally (a load that waits on the per-env flag does not pipeline: the fused
-                // instantiation ran 40 % behind the plain one); the few freshly reset maps drop what they read
-                if (MODE == FM_STEP) v = reinterpret_cast<const float4*>(vis)[q];
-                if (fresh) {                                                // fused reset: v4:112-119 at the placed ball
-                    v = make_float4(0.f, 0.f, 0.f, 0.f);
-                    if (!V5) {                                              // v5:130 restarts from zeros, no window
-                        const int rx = rcen[le * 2], ry = rcen[le * 2 + 1];
-                        v.x = update(v.x, c0, rx, ry);
-                        v.y = update(v.y, c0 + 1, rx, ry);
-                        v.z = update(v.z, c0 + 2, rx, ry);
-                        v.w = update(v.w, c0 + 3, rx, ry);
+            // UNR independent loads in flight per lane before the first is used: with one load -> update -> store
+            // round trip at a time a wave lived 66 us (20 trips of ~3 us under load) and the stream ran at 5.1 TB/s,
+            // bound by latency, not by bandwidth (SQ_WAIT_ANY 75 % of the wave cycles)
+            constexpr int UNR = 4;
+            const int nq4 = total >> 2;
+            for (int q0 = tid; q0 < nq4; q0 += UNR * LMAZE_BLOCK) {
+                float4 v[UNR];
+                int les[UNR], c0s[UNR], fls[UNR];
+                bool act[UNR];
+#pragma unroll
+                for (int u = 0; u < UNR; ++u) {
+                    const int q = q0 + u * LMAZE_BLOCK;
+                    const int f0 = q << 2;
+                    les[u] = f0 / CELLS;
+                    c0s[u] = f0 - les[u] * CELLS;
+                    fls[u] = q < nq4 ? flags[les[u]] : 1;
+                    const bool fresh = MODE == FM_STEP && AR && (fls[u] & 4);
+                    act[u] = !(fls[u] & 1) && !(V5 && MODE == FM_STEP && !(fls[u] & 2) && !fresh);   // else: map unchanged
+                }
+#pragma unroll
+                for (int u = 0; u < UNR; ++u) {
+                    v[u] = make_float4(0.f, 0.f, 0.f, 0.f);                 // reset: v4:112 / v5:130
+                    // the few freshly reset maps of a fused step are loaded too and drop what they read (a load that
+                    // waits on more than the skip / update flag does not pipeline)
+                    if (MODE == FM_STEP && act[u]) {
+#ifdef LMAZE_EXPERIMENT
+                        if (xp & 128) {
+                            typedef float v4f __attribute__((ext_vector_type(4)));
+                            const v4f t = __builtin_nontemporal_load(reinterpret_cast<const v4f*>(vis) + q0 + u * LMAZE_BLOCK);
+                            v[u] = make_float4(t.x, t.y, t.z, t.w);
+                        } else
+#endif
+                        v[u] = reinterpret_cast<const float4*>(vis)[q0 + u * LMAZE_BLOCK];
                     }
                 }
-                if (!(V5 && MODE == FM_RESET) && !nostep && !(V5 && MODE == FM_STEP && !upd)) {   // v5 adds no window at reset
-                    v.x = update(v.x, c0, cx, cy);
-                    v.y = update(v.y, c0 + 1, cx, cy);
-                    v.z = update(v.z, c0 + 2, cx, cy);
-                    v.w = update(v.w, c0 + 3, cx, cy);
+#pragma unroll
+                for (int u = 0; u < UNR; ++u) {
+                    if (!act[u]) continue;
+                    const int le = les[u], c0 = c0s[u], fl = fls[u];
+                    const bool upd = fl & 2;
+                    const bool fresh = MODE == FM_STEP && AR && (fl & 4), nostep = MODE == FM_STEP && AR && (fl & 8);
+                    if (fresh) {                                            // fused reset: v4:112-119 at the placed ball
+                        v[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+                        if (!V5) update4(v[u], c0, rcen[le * 2], rcen[le * 2 + 1]);   // v5:130 restarts from zeros, no window
+                    }
+                    if (!(V5 && MODE == FM_RESET) && !nostep && !(V5 && MODE == FM_STEP && !upd))   // v5 adds no window at reset
+                        update4(v[u], c0, cen[le * 4], cen[le * 4 + 1]);
+#ifdef LMAZE_EXPERIMENT
+                    if (xp & 64) {
+                        typedef float v4f __attribute__((ext_vector_type(4)));
+                        const v4f t = {v[u].x, v[u].y, v[u].z, v[u].w};
+                        __builtin_nontemporal_store(t, reinterpret_cast<v4f*>(vis) + q0 + u * LMAZE_BLOCK);
+                    } else
+#endif
+                    reinterpret_cast<float4*>(vis)[q0 + u * LMAZE_BLOCK] = v[u];
                 }
-                reinterpret_cast<float4*>(vis)[q] = v;
-                keep(le, c0, v.x); keep(le, c0 + 1, v.y); keep(le, c0 + 2, v.z); keep(le, c0 + 3, v.w);
             }
         } else {
             for (int f = tid; f < total; f += LMAZE_BLOCK) {
@@ -629,32 +712,39 @@ __global__ __launch_bounds__(LMAZE_BLOCK) void foveal_kernel(const FovealArgs a)
                 if (!(V5 && MODE == FM_RESET) && !nostep && !(V5 && MODE == FM_STEP && !upd))
                     v = update(v, c, cen[le * 4], cen[le * 4 + 1]);
                 vis[f] = v;
-                keep(le, c, v);
             }
         }
-        if (V5 && MODE == FM_STEP) {  // unchanged maps: gather the two windows straight from HBM
-            for (int i = tid; i < nb * 2 * W25; i += LMAZE_BLOCK) {
-                const int le = i / (2 * W25);
-                if (flags[le] & (AR ? 7 : 3)) continue;     // skipped, streamed, or freshly zeroed (kept by the stream)
-                const int r = i - le * 2 * W25;
-                const int w = r / W25, cell = r - w * W25;
-                const int x = cen[le * 4 + 2 * w] - 2 + cell / FOV, y = cen[le * 4 + 2 * w + 1] - 2 + cell % FOV;
-                if (x >= 0 && y >= 0 && x < G && y < G) vwin[i] = vis[le * CELLS + x * G + y];
+        __syncthreads();   // the maps this workgroup has just stored are visible to all its lanes; vwin is zeroed
+        for (int i = tid; i < nb * 2 * FOV; i += LMAZE_BLOCK) {
+            const int le = i / (2 * FOV);
+            if (flags[le] & 1) continue;                // skipped env: its observation is not written
+            const int r = i - le * 2 * FOV;
+            const int w = r / FOV, row = r - w * FOV;
+            const int x = cen[le * 4 + 2 * w] - 2 + row, y0 = cen[le * 4 + 2 * w + 1] - 2;
+            if (x < 0 || x >= G) continue;              // outside the array: stays 0
+            const float* src = vis + (size_t)le * CELLS + x * G;
+            float* dst = vwin + le * 2 * W25 + w * W25 + row * FOV;
+            if (y0 >= 0 && y0 + FOV <= G) {             // 5 adjacent floats: 2 load instructions
+                struct __attribute__((packed, aligned(4))) Row5 { float v[FOV]; };
+                const Row5 t = *reinterpret_cast<const Row5*>(src + y0);
+#pragma unroll
+                for (int j = 0; j < FOV; ++j) dst[j] = t.v[j];
+            } else {
+                for (int j = 0; j < FOV; ++j)
+                    if (y0 + j >= 0 && y0 + j < G) dst[j] = src[y0 + j];
             }
         }
         __syncthreads();
     }
 
     // ---------------- phase 3: render float[nb*C*25], contiguous, 16-byte stores ----------------
+    // float `rem` of env le's observation: a bit of the string, or -- visit planes 2 and 6 of v4-v6, sampled live at
+    // the current / "previous" window -- one of the env's 2 x 25 samples
     auto element = [&](int le, int rem) -> float {
-        if (!V4) {
-            const int f = le * PERENV + rem;
-            return ((obits[f >> 5] >> (f & 31)) & 1u) ? 1.0f : 0.0f;
-        }
-        const int ch = rem / W25, cell = rem - ch * W25;
-        if (ch == 2 || ch == 6)   // visit map, sampled live at the current / "previous" window
-            return vwin[le * 2 * W25 + (ch == 2 ? 0 : W25) + cell];
-        return ((masks[le * 8 + ch] >> cell) & 1u) ? 1.0f : 0.0f;
+        if (V4 && rem >= 2 * W25 && rem < 3 * W25) return vwin[le * 2 * W25 + rem - 2 * W25];
+        if (V4 && rem >= 6 * W25) return vwin[le * 2 * W25 + rem - 5 * W25];
+        const int f = le * PERENV + rem;
+        return ((obits[f >> 5] >> (f & 31)) & 1u) ? 1.0f : 0.0f;
     };
     float* obs = a.b.obs + (size_t)blockbase * PERENV;
     const int R = (V5 && MODE == FM_PLANNER) ? 0 : nb * PERENV;   // plannerStep returns only the local observation
@@ -688,10 +778,17 @@ __global__ __launch_bounds__(LMAZE_BLOCK) void foveal_kernel(const FovealArgs a)
             // (masks per plane and a division per float made this loop ALU-bound: 1 210 VALU per wave on v2)
             nibble_floats(obits, q, v);
         } else {
+            // v4-v6: five 0/1 planes and two float planes per env -- the nibble as above, then the floats that fall
+            // into a visit plane are replaced by their samples (2 of 7 planes; a third of the stores touch one)
+            nibble_floats(obits, q, v);
+            if (rem + 3 >= 2 * W25 && !(rem >= 3 * W25 && rem + 3 < 6 * W25)) {
 #pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                v[k] = element(le, rem);
-                if (++rem == PERENV) { rem = 0; ++le; }
+                for (int k = 0; k < 4; ++k) {
+                    int r = rem + k, l2 = le;
+                    if (r >= PERENV) { r -= PERENV; ++l2; }
+                    if (r >= 2 * W25 && r < 3 * W25) v[k] = vwin[l2 * 2 * W25 + r - 2 * W25];
+                    else if (r >= 6 * W25) v[k] = vwin[l2 * 2 * W25 + r - 5 * W25];
+                }
             }
         }
         if (a.nt) {  // large batches: the observation cannot stay in the Infinity Cache, stream it (+6...12 %)
@@ -722,7 +819,7 @@ __global__ __launch_bounds__(LMAZE_BLOCK) void foveal_kernel(const FovealArgs a)
             const int le = f / PERLOC;
             if (flags[le] & 1) continue;
             float v[4];
-            nibble_floats(obits, q, v);
+            nibble_floats(lbits, q, v);
             reinterpret_cast<float4*>(loc)[q] = make_float4(v[0], v[1], v[2], v[3]);
         }
     }
@@ -876,13 +973,9 @@ template <int VARIANT, int MODE, int EPB>
 static hipError_t launch_foveal_one(const FovealArgs& a, hipStream_t s) {
     const int cells = a.p.grid * a.p.grid;
     const int L = VARIANT == LMAZE_VARIANT_V1 ? 1 : a.p.n_layouts;
-    // masks 32 B + lmasks 16 B + centres 8 B + flags 4 B + reset centre 4 B per env, row masks, layout characters, visit samples
+    // obs bit string 32 B + obs_local bit string 16 B + centres 8 B + flags 4 B + reset centre 4 B per env, row masks, layout characters, visit samples
     size_t lds = (size_t)EPB * 64 + (3 * (size_t)L * a.p.grid + 2 * (size_t)a.p.grid) * 8 + (size_t)((L * cells + 15) & ~15);
     if (VARIANT == LMAZE_VARIANT_V4 || VARIANT == LMAZE_VARIANT_V5) lds += (size_t)EPB * 2 * W25 * 4;
-    {   // the bit string of the 0/1 planes (v1, v2: obs; v5/v6: obs_local), see foveal_kernel
-        const int per = VARIANT == LMAZE_VARIANT_V1 ? 4 * W25 : (VARIANT == LMAZE_VARIANT_V2 ? 5 * W25 : 4 * W25);
-        lds += (((size_t)EPB * per + 31) / 32 + 1) * 4 + 16;
-    }
     const int64_t blocks = (a.n + EPB - 1) / EPB;
     if (!grid_ok(blocks)) return hipErrorInvalidConfiguration;
     FovealArgs b = a;

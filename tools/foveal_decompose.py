@@ -18,6 +18,9 @@ modes = {"full": 0, "no_setup": 1, "no_stores": 4, "no_phase1": 8, "stores_only"
 if os.environ.get("DECOMPOSE_VISIT"):     # v4 / v5: the visit-map stream (bit 13) as well
     modes = {"full": 0, "no_setup": 1, "no_stores": 4, "no_phase1": 8, "no_visit_stream": 32, "stores_only": 41,
              "visit_stream only": 13, "phase1 only": 37, "phase1 + visit": 5}
+if os.environ.get("DECOMPOSE_NTMAP"):     # v4: non-temporal accesses for the visit-map stream
+    modes = {"full": 0, "nt map stores": 64, "nt map loads": 128, "nt both": 192, "visit only": 13, "visit only nt both": 13 + 192,
+             "visit only nt stores": 13 + 64}
 if os.environ.get("DECOMPOSE_CAPS"):      # second study: does capping the resident workgroups help the bare store stream?
     modes = {"full": 0, "stores_only": 9, "full interleaved-pieces": 16, "stores_only interleaved-pieces": 25,
              "stores_only interleaved-pieces plain": 27}
@@ -50,7 +53,7 @@ for variant in (sys.argv[1:] or ["v2", "v1"]):
     snap = env._state.clone()
     out = {}
     for rnd in range(2):
-        for epb, name, cap in [(e, m, c) for e in ((4,) if os.environ.get('DECOMPOSE_CAPS') else (2, 3, 4)) for m in modes for c in CAPS]:
+        for epb, name, cap in [(e, m, c) for e in ((4,) if os.environ.get('DECOMPOSE_CAPS') else ((3,) if os.environ.get('DECOMPOSE_NTMAP') else (2, 3, 4))) for m in modes for c in CAPS]:
             if True:
                 xp = modes[name]
                 env._state.copy_(snap)
