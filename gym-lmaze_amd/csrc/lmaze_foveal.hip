@@ -612,39 +612,45 @@ __global__ __launch_bounds__(LMAZE_BLOCK) void foveal_kernel(const FovealArgs a)
     const bool some_skipped = any_skip != 0;
 
     // ---------------- phase 2 (v4-v6): the visit maps, v4:116-119 / v4:211-214 / v5:313-318 ----------------
-    // Envs whose map changes are streamed through (load, + window, halve, store; 16-byte accesses); then, after a
-    // barrier, the 2 x 25 cells the two observation windows show are gathered for every env, one lane per window
-    // row -- from the lines the workgroup has just written, or, for maps that do not change (v5/v6 without
-    // localDone), from HBM.  (Round 1 tested every streamed cell against both windows on the way: two thirds of
-    // the stream's 170 VALU instructions per 16 bytes, on the kernel's critical resource.)
+    // Envs whose map changes are streamed through (load, + window, halve, store; 16-byte accesses, UNR loads in
+    // flight per lane) and the cells that fall in their two observation windows are kept in LDS on the way; envs
+    // whose map does not change (v5/v6 without localDone) only have those 2 x 25 cells gathered, one lane per
+    // window row.  Every byte of a map is read and written at most once per launch.
 #ifdef LMAZE_EXPERIMENT
     if (!(xp & 32))
 #endif
     if (V4 && !(V5 && MODE == FM_PLANNER)) {
         float* vis = a.b.visit + (size_t)blockbase * CELLS;
         const int total = nb * CELLS;
-        // (v + w) * 0.5f in float32 == the reference's float64 round trip: the add rounds once, the halving is exact
-        auto update4 = [&](float4& v, int c0, int cx, int cy) {
+        // One cell: v <- (v + [cell in the 5x5 window at (cx, cy)]) / 2 when `add` -- float32 add + exact halving ==
+        // the reference's float64 round trip -- and, when `le` >= 0, the new value goes to the env's window samples
+        // if the current window (centre cx, cy: the window just added) or the "previous" one (px, py) shows the cell.
+        auto cell = [&](float v, int x, int y, int cx, int cy, bool add, int le, int px, int py) -> float {
+            const int dx = x - cx + 2, dy = y - cy + 2;
+            const bool in = (unsigned)dx <= 4u && (unsigned)dy <= 4u;
+            if (add) v = (v + (in ? 1.0f : 0.0f)) * 0.5f;
+            if (le >= 0) {
+                if (in) vwin[le * 2 * W25 + dx * FOV + dy] = v;
+                const int ex = x - px + 2, ey = y - py + 2;
+                if ((unsigned)ex <= 4u && (unsigned)ey <= 4u) vwin[le * 2 * W25 + W25 + ex * FOV + ey] = v;
+            }
+            return v;
+        };
+        auto update4 = [&](float4& v, int c0, int cx, int cy, bool add, int le, int px, int py) {
             int x = c0 / G, y = c0 - x * G;
             float* p = &v.x;
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
-                const float w = ((unsigned)(x - cx + 2) <= 4u && (unsigned)(y - cy + 2) <= 4u) ? 1.0f : 0.0f;
-                p[k] = (p[k] + w) * 0.5f;
+                p[k] = cell(p[k], x, y, cx, cy, add, le, px, py);
                 if (++y == G) { y = 0; ++x; }
             }
         };
-        auto update = [&](float v, int c, int cx, int cy) -> float {
-            const int x = c / G, y = c - x * G;
-            const float w = ((unsigned)(x - cx + 2) <= 4u && (unsigned)(y - cy + 2) <= 4u) ? 1.0f : 0.0f;
-            return (v + w) * 0.5f;
-        };
         // window cells outside the array read 0 (the padded layouts never get there)
         for (int i = tid; i < nb * 2 * W25; i += LMAZE_BLOCK) vwin[i] = 0.0f;
+        __syncthreads();
         if ((CELLS & 3) == 0) {  // a 16-byte access never straddles two envs
             // UNR independent loads in flight per lane before the first is used: with one load -> update -> store
-            // round trip at a time a wave lived 66 us (20 trips of ~3 us under load) and the stream ran at 5.1 TB/s,
-            // bound by latency, not by bandwidth (SQ_WAIT_ANY 75 % of the wave cycles)
+            // round trip at a time a wave lived 66 us (20 trips of ~3 us under load), 75 % of it in s_waitcnt
             constexpr int UNR = 4;
             const int nq4 = total >> 2;
             for (int q0 = tid; q0 < nq4; q0 += UNR * LMAZE_BLOCK) {
@@ -685,10 +691,10 @@ __global__ __launch_bounds__(LMAZE_BLOCK) void foveal_kernel(const FovealArgs a)
                     const bool fresh = MODE == FM_STEP && AR && (fl & 4), nostep = MODE == FM_STEP && AR && (fl & 8);
                     if (fresh) {                                            // fused reset: v4:112-119 at the placed ball
                         v[u] = make_float4(0.f, 0.f, 0.f, 0.f);
-                        if (!V5) update4(v[u], c0, rcen[le * 2], rcen[le * 2 + 1]);   // v5:130 restarts from zeros, no window
+                        if (!V5) update4(v[u], c0, rcen[le * 2], rcen[le * 2 + 1], true, -1, 0, 0);   // v5:130 restarts from zeros, no window
                     }
-                    if (!(V5 && MODE == FM_RESET) && !nostep && !(V5 && MODE == FM_STEP && !upd))   // v5 adds no window at reset
-                        update4(v[u], c0, cen[le * 4], cen[le * 4 + 1]);
+                    const bool add = !(V5 && MODE == FM_RESET) && !nostep && !(V5 && MODE == FM_STEP && !upd);   // v5 adds no window at reset
+                    update4(v[u], c0, cen[le * 4], cen[le * 4 + 1], add, le, cen[le * 4 + 2], cen[le * 4 + 3]);
 #ifdef LMAZE_EXPERIMENT
                     if (xp & 64) {
                         typedef float v4f __attribute__((ext_vector_type(4)));
@@ -707,31 +713,35 @@ __global__ __launch_bounds__(LMAZE_BLOCK) void foveal_kernel(const FovealArgs a)
                 const bool skip = fl & 1, upd = fl & 2;
                 const bool fresh = MODE == FM_STEP && AR && (fl & 4), nostep = MODE == FM_STEP && AR && (fl & 8);
                 if (skip || (V5 && MODE == FM_STEP && !upd && !fresh)) continue;
+                const int x = c / G, y = c - x * G;
                 float v = (MODE == FM_STEP && !fresh) ? vis[f] : 0.0f;
-                if (fresh && !V5) v = update(v, c, rcen[le * 2], rcen[le * 2 + 1]);
-                if (!(V5 && MODE == FM_RESET) && !nostep && !(V5 && MODE == FM_STEP && !upd))
-                    v = update(v, c, cen[le * 4], cen[le * 4 + 1]);
+                if (fresh && !V5) v = cell(v, x, y, rcen[le * 2], rcen[le * 2 + 1], true, -1, 0, 0);
+                const bool add = !(V5 && MODE == FM_RESET) && !nostep && !(V5 && MODE == FM_STEP && !upd);
+                v = cell(v, x, y, cen[le * 4], cen[le * 4 + 1], add, le, cen[le * 4 + 2], cen[le * 4 + 3]);
                 vis[f] = v;
             }
         }
-        __syncthreads();   // the maps this workgroup has just stored are visible to all its lanes; vwin is zeroed
-        for (int i = tid; i < nb * 2 * FOV; i += LMAZE_BLOCK) {
-            const int le = i / (2 * FOV);
-            if (flags[le] & 1) continue;                // skipped env: its observation is not written
-            const int r = i - le * 2 * FOV;
-            const int w = r / FOV, row = r - w * FOV;
-            const int x = cen[le * 4 + 2 * w] - 2 + row, y0 = cen[le * 4 + 2 * w + 1] - 2;
-            if (x < 0 || x >= G) continue;              // outside the array: stays 0
-            const float* src = vis + (size_t)le * CELLS + x * G;
-            float* dst = vwin + le * 2 * W25 + w * W25 + row * FOV;
-            if (y0 >= 0 && y0 + FOV <= G) {             // 5 adjacent floats: 2 load instructions
-                struct __attribute__((packed, aligned(4))) Row5 { float v[FOV]; };
-                const Row5 t = *reinterpret_cast<const Row5*>(src + y0);
+        if (V5 && MODE == FM_STEP) {
+            // unchanged maps: the two windows straight from HBM, one lane per window row (5 adjacent floats, 2 load
+            // instructions; the per-element gather of round 1 made this phase 40 % of a v5 launch)
+            for (int i = tid; i < nb * 2 * FOV; i += LMAZE_BLOCK) {
+                const int le = i / (2 * FOV);
+                if (flags[le] & (AR ? 7 : 3)) continue;     // skipped, streamed, or freshly zeroed (kept by the stream)
+                const int r = i - le * 2 * FOV;
+                const int w = r / FOV, row = r - w * FOV;
+                const int x = cen[le * 4 + 2 * w] - 2 + row, y0 = cen[le * 4 + 2 * w + 1] - 2;
+                if (x < 0 || x >= G) continue;              // outside the array: stays 0
+                const float* src = vis + (size_t)le * CELLS + x * G;
+                float* dst = vwin + le * 2 * W25 + w * W25 + row * FOV;
+                if (y0 >= 0 && y0 + FOV <= G) {
+                    struct __attribute__((packed, aligned(4))) Row5 { float v[FOV]; };
+                    const Row5 t = *reinterpret_cast<const Row5*>(src + y0);
 #pragma unroll
-                for (int j = 0; j < FOV; ++j) dst[j] = t.v[j];
-            } else {
-                for (int j = 0; j < FOV; ++j)
-                    if (y0 + j >= 0 && y0 + j < G) dst[j] = src[y0 + j];
+                    for (int j = 0; j < FOV; ++j) dst[j] = t.v[j];
+                } else {
+                    for (int j = 0; j < FOV; ++j)
+                        if (y0 + j >= 0 && y0 + j < G) dst[j] = src[y0 + j];
+                }
             }
         }
         __syncthreads();

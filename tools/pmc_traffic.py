@@ -63,7 +63,8 @@ def main():
     hbm = int(round(wkb * 1024 + 2 * fkb * 1024))
     rec = {"round": args.round, "kernel": kw[0].split("(")[0][:100], "write_size_kb": wkb, "fetch_size_kb": fkb,
            "hbm_bytes_per_launch": hbm, "algorithmic_bytes_per_launch": args.algorithmic,
-           "dispatches": [w[kw[0]][0], f[kf[0]][0]]}
+           "dispatches": [w[kw[0]][0], f[kf[0]][0]],
+           "files": "profiles/r%02d/%s_{write,fetch}_size.csv" % (args.round, os.path.basename(args.out_prefix) if args.out_prefix else args.key)}
     path = os.path.join(ROOT, "profiles", "traffic.json")
     tj = json.load(open(path)) if os.path.exists(path) else {}
     tj[args.key] = rec
