@@ -1020,7 +1020,7 @@ static hipError_t launch_foveal_one(const FovealArgs& a, hipStream_t s) {
 // launch_hint bits 4-7 (plain step only): envs per workgroup, 2: 32 ... 5: 256; anything else = the default below
 template <int VARIANT>
 static bool launch_step_hinted(const FovealArgs& a, hipStream_t s, hipError_t& rc) {
-    if (a.auto_reset) return false;
+    if (a.auto_reset && VARIANT != LMAZE_VARIANT_V5) return false;   // v1/v2/v4 fused reset: one measured size each (below)
     switch ((a.p.launch_hint >> 4) & 15) {
         case 2: rc = launch_foveal_one<VARIANT, FM_STEP, 32>(a, s); return true;
         case 3: rc = launch_foveal_one<VARIANT, FM_STEP, 64>(a, s); return true;
