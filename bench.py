@@ -373,6 +373,10 @@ def main():
         # warm the device as LmazeVecEnv.autotune() does for the grid workloads (cold clocks)
         with torch.cuda.device(dev):
             run(0, 150)
+        if args.launch_hint is None and not args.no_autotune:
+            # untimed, state restored: (envs per workgroup, workgroups per CU) for this device, on the tensors the timed
+            # steps read -- as LmazeVecEnv.autotune() does for the grid workloads
+            tuned = env.autotune(actions, goals=goals, auto_reset=args.auto_reset)
     else:
         if args.workload == "c2":
             layout = pkg.layouts.to_codes(pkg.layouts.GRID_8_BORDERED)   # lmaze_env.py:28-35 literal, bordered
@@ -533,7 +537,7 @@ def main():
                        if dist is not None else None,
                        "launch_hint": int(env.params.launch_hint),
                        "perenv_kernel": perenv_kernel,
-                       "autotune_ms": {("%dx%d" % k if isinstance(k, tuple) else str(k)): round(v, 5)
+                       "autotune_ms": {("%dx%d" % k if isinstance(k, tuple) else ("0x%02x" % k if foveal else str(k))): round(v, 5)
                                        for k, v in (tuned or {}).items()}},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_source,

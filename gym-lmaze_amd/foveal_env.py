@@ -48,6 +48,7 @@ class LmazeFovealVecEnv(object):
         self.channels = spec["channels"]
         self.expansion = spec["expansion"]
         self.seed, self.env_base, self._epoch = int(seed), int(env_base), 0
+        self.tuned_policy = None     # launch_hint chosen by autotune()
         tabs = [L.to_codes(t) for t in (layouts if layouts is not None else spec["layouts"])]
         G = tabs[0].shape[0]
         pad = 2 if variant == "v1" else 2   # the 5x5 window must stay inside the array
@@ -225,6 +226,64 @@ class LmazeFovealVecEnv(object):
             rc = _abi.lib.lmaze_v5_hier_step(self._pp, self._p_layouts, action_ptr, goal_ptr, self._pb, self.num_envs,
                                              self.seed & (2 ** 64 - 1), epoch, self.env_base, e_in, e_out, self._stream())
         _abi.check("lmaze_v5_hier_step", rc)
+
+    # launch policies autotune() tries: LmazeFovealParams.launch_hint = (envs-per-workgroup code << 4) | workgroups per CU
+    CANDIDATES = (0x00, 0x30, 0x34, 0x35, 0x36, 0x43, 0x44, 0x45, 0x40)
+
+    def autotune(self, actions, goals=None, auto_reset=False, steps=24, candidates=None, warm=100, rounds=3):
+        """Pick LmazeFovealParams.launch_hint by timing real steps with HIP events on the caller's own action tensor
+        (int32[T,N] on the device, rows cycled; `goals` likewise for the v5/v6 two-level step); state and visit maps
+        are snapshotted and restored, so results are unaffected.  The best (envs per workgroup, workgroups per CU)
+        pair moves from device to device -- v2 at 1M envs: uncapped 96 us on one box and 102 on the next, 6 per CU 95
+        and 95, 5 per CU 99 and 90 -- exactly as for the grid kernels (LmazeVecEnv.autotune).  The median of `rounds`
+        interleaved passes counts and the library default (hint 0) is kept unless another hint beats it by more than
+        1.5 %.  Returns {hint: ms}."""
+        N = self.num_envs
+        for t in (actions, goals):
+            if t is not None and not (isinstance(t, torch.Tensor) and t.dtype == torch.int32 and t.dim() == 2
+                                      and t.shape[1] == N and t.device == self.device and t.is_contiguous()):
+                raise ValueError("autotune() wants contiguous int32[T,N] tensors on %s" % (self.device,))
+        if self._two_level and goals is None:
+            raise ValueError("v5/v6: autotune() times the two-level step and needs planner goals")
+        cands = list(candidates or self.CANDIDATES)
+        R = int(actions.shape[0])
+        snap = (self._state.clone(), None if self.visit is None else self.visit.clone(), self._epoch)
+        k = [0]
+
+        def run(n):
+            for _ in range(n):
+                r = k[0] % R
+                if self._two_level:
+                    self.hier_step_raw(actions[r].data_ptr(), goals[r % goals.shape[0]].data_ptr())
+                else:
+                    self.step_raw(actions[r].data_ptr(), auto_reset=auto_reset)
+                k[0] += 1
+
+        timings = {}
+        with self._guard():
+            run(int(warm))
+            for _round in range(int(rounds)):          # interleaved passes; the median of a candidate's passes counts
+                for h in cands:
+                    self.params.launch_hint = int(h)
+                    run(1)
+                    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    e0.record()
+                    run(steps)
+                    e1.record()
+                    e1.synchronize()
+                    ms = e0.elapsed_time(e1) / steps
+                    timings.setdefault(h, []).append(ms)
+            self._state.copy_(snap[0])
+            if snap[1] is not None:
+                self.visit.copy_(snap[1])
+            self._epoch = snap[2]
+        timings = {h: sorted(v)[len(v) // 2] for h, v in timings.items()}
+        best = min(timings, key=timings.get)
+        if 0 in timings and timings[best] > 0.985 * timings[0]:
+            best = 0
+        self.params.launch_hint = int(best)
+        self.tuned_policy = best
+        return timings
 
     def reset(self, mask=None, place=True, seed=None):
         """Masked reset; place=False keeps the caller's ball/goal/layout_id (set_state)."""

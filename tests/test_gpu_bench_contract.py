@@ -63,6 +63,8 @@ def test_bench_line(flags):
     assert d["per_rank_ms_per_step"]["min"] <= d["per_rank_ms_per_step"]["max"] and len(d["per_rank_ms_per_step"]["all"]) == 1
     assert d["config"]["world_size_seen"] == 1 and "traffic_source" in r and "perenv_kernel" in d["config"]
     assert (r["traffic"] is None) == (r["traffic_source"] is None)
+    if wl in ("v2", "v5"):          # the foveal workloads pick their launch policy before the timed region, as C3 does
+        assert len(d["config"]["autotune_ms"]) >= 5 and ("0x%02x" % d["config"]["launch_hint"]) in d["config"]["autotune_ms"]
     if wl == "c5":
         assert "wave/register-tiled" in d["config"]["perenv_kernel"]
     if wl == "v5":

@@ -619,3 +619,37 @@ def test_foveal_bad_launch_hint_is_refused():
     e.params.launch_hint = 0x100
     with pytest.raises(PKG._abi.LmazeError):
         e.step(torch.zeros(8, dtype=torch.int32))
+
+
+@pytest.mark.parametrize("variant", ["v2", "v5"])
+def test_foveal_autotune_picks_a_hint_and_leaves_no_trace(variant):
+    """LmazeFovealVecEnv.autotune() times the launch policies on real steps and restores state, visit maps and the
+    reset epoch: the rollout after it equals the rollout of an env that never tuned."""
+    N, T = 1 << 16, 6
+    tuned, plain = PKG.LmazeFovealVecEnv(N, variant=variant, seed=12), PKG.LmazeFovealVecEnv(N, variant=variant, seed=12)
+    gen = torch.Generator(device="cuda").manual_seed(1)
+    hi = 4 if variant == "v5" else 25
+    acts = torch.randint(0, hi, (8, N), dtype=torch.int32, device="cuda", generator=gen)
+    goals = torch.randint(0, 25, (8, N), dtype=torch.int32, device="cuda", generator=gen) if variant == "v5" else None
+    for e in (tuned, plain):
+        if variant == "v5":
+            e.foveal_done.fill_(True)
+    ms = tuned.autotune(acts, goals=goals, steps=4, warm=10)
+    assert set(ms) == set(tuned.CANDIDATES) and all(v > 0 for v in ms.values())
+    best = min(ms, key=ms.get)
+    # the fastest hint, or the library default when nothing beats it by more than 1.5 %
+    assert tuned.params.launch_hint == tuned.tuned_policy and tuned.tuned_policy in (best, 0)
+    assert tuned.tuned_policy == best or ms[best] > 0.985 * ms[0]
+    assert tuned._epoch == plain._epoch
+    for t in range(T):
+        for e in (tuned, plain):
+            if variant == "v5":
+                e.hier_step(acts[t], goals[t])
+            else:
+                e.step(acts[t])
+    ht, hp = tuned.host_state(), plain.host_state()
+    for k in ht:
+        assert (ht[k].view(np.uint8) == hp[k].view(np.uint8)).all(), k
+    assert (_bits(_np(tuned.obs)) == _bits(_np(plain.obs))).all()
+    if tuned.visit is not None:
+        assert (_bits(_np(tuned.visit)) == _bits(_np(plain.visit))).all()

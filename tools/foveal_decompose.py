@@ -21,10 +21,12 @@ if os.environ.get("DECOMPOSE_VISIT"):     # v4 / v5: the visit-map stream (bit 1
 if os.environ.get("DECOMPOSE_NTMAP"):     # v4: non-temporal accesses for the visit-map stream
     modes = {"full": 0, "nt map stores": 64, "nt map loads": 128, "nt both": 192, "visit only": 13, "visit only nt both": 13 + 192,
              "visit only nt stores": 13 + 64}
+if os.environ.get("DECOMPOSE_PLAIN"):     # plain against non-temporal observation stores, whole kernel, caps x sizes
+    modes = {"full": 0, "full plain-stores": 2}
 if os.environ.get("DECOMPOSE_CAPS"):      # second study: does capping the resident workgroups help the bare store stream?
     modes = {"full": 0, "stores_only": 9, "full interleaved-pieces": 16, "stores_only interleaved-pieces": 25,
              "stores_only interleaved-pieces plain": 27}
-CAPS = (0, 3, 4, 5, 6) if os.environ.get("DECOMPOSE_CAPS") else (0,)
+CAPS = (0, 3, 4, 5, 6) if (os.environ.get("DECOMPOSE_CAPS") or os.environ.get("DECOMPOSE_PLAIN")) else (0,)
 for variant in (sys.argv[1:] or ["v2", "v1"]):
     env = pkg.LmazeFovealVecEnv(N, variant=variant, seed=1)
     hi = 4 if variant in ("v1", "v5") else 25
@@ -53,7 +55,7 @@ for variant in (sys.argv[1:] or ["v2", "v1"]):
     snap = env._state.clone()
     out = {}
     for rnd in range(2):
-        for epb, name, cap in [(e, m, c) for e in ((4,) if os.environ.get('DECOMPOSE_CAPS') else ((3,) if os.environ.get('DECOMPOSE_NTMAP') else (2, 3, 4))) for m in modes for c in CAPS]:
+        for epb, name, cap in [(e, m, c) for e in ((4,) if os.environ.get('DECOMPOSE_CAPS') else ((3,) if os.environ.get('DECOMPOSE_NTMAP') else ((3, 4, 5) if os.environ.get('DECOMPOSE_PLAIN') else (2, 3, 4)))) for m in modes for c in CAPS]:
             if True:
                 xp = modes[name]
                 env._state.copy_(snap)

@@ -21,22 +21,24 @@ $B --auto-reset --no-cpu-baseline > $OUT/bench_c3_autoreset.json 2>/dev/null
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_c3 -- $B --launch-hint $H --no-cpu-baseline > $OUT/bench_c3_under_rocprofv3.json 2> $OUT/stats_c3.err; echo "stats c3 rc=$?"
 fi
 for w in c2 c5 v1 v2 v4 v5; do has $w || continue; $B --workload $w > $OUT/bench_$w.json 2> $OUT/bench_$w.err; echo "$w rc=$?"; done
+# the launch policy each un-profiled line was tuned to on THIS box: fixed for every profiled pass below
+hint() { python3 -c "import json; print(json.load(open('$OUT/bench_$1.json'))['config']['launch_hint'])" 2>/dev/null || echo 0; }
 has c2 && $B --workload c2 --graph --no-cpu-baseline > $OUT/bench_c2_graph.json 2>/dev/null
 for w in v1 v2 v4 v5 c5 c2; do
   has $w || continue
-  rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_$w -- $B --workload $w --no-cpu-baseline > $OUT/bench_${w}_under_rocprofv3.json 2> $OUT/stats_$w.err; echo "stats $w rc=$?"
+  rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_$w -- $B --workload $w --launch-hint $(hint $w) --no-cpu-baseline > $OUT/bench_${w}_under_rocprofv3.json 2> $OUT/stats_$w.err; echo "stats $w rc=$?"
 done
 # PMC passes (separate: WRITE_SIZE and FETCH_SIZE do not fit the TCC slots together)
 for w in c3 v1 v2 v4 v5 c5; do
   has $w || continue
-  X="--workload $w"; [ $w = c3 ] && X="--launch-hint $H"
+  X="--workload $w --launch-hint $(hint $w)"; [ $w = c3 ] && X="--launch-hint $H"
   for c in WRITE_SIZE FETCH_SIZE; do
     rocprofv3 --pmc $c --kernel-trace --output-format csv -d $OUT/pmc_${w}_$c -- $B $X --steps 20 --warmup 5 --no-cpu-baseline > $OUT/pmc_${w}_$c.json 2> $OUT/pmc_${w}_$c.err; echo "pmc $w $c rc=$?"
   done
 done
 for w in c3 v2 v4 v5; do
   has $w || continue
-  X="--workload $w"; [ $w = c3 ] && X="--launch-hint $H"
+  X="--workload $w --launch-hint $(hint $w)"; [ $w = c3 ] && X="--launch-hint $H"
   rocprofv3 --pmc SQ_INSTS_VALU SQ_WAVES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_INSTS_LDS SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_WAVE_CYCLES --kernel-trace --output-format csv -d $OUT/sq_$w -- $B $X --steps 20 --warmup 5 --no-cpu-baseline > $OUT/sq_$w.json 2> $OUT/sq_$w.err; echo "sq $w rc=$?"
 done
 # keep the merge small: summaries only (the raw counter files are tens of MB)
