@@ -188,16 +188,21 @@ class LmazeFovealVecEnv(object):
         _abi.check("lmaze_foveal_step", rc)
         return self.obs, self.reward, self.done, actions
 
-    def step_raw(self, action_ptr, auto_reset=False):
+    def step_raw(self, action_ptr, auto_reset=False, epoch_slot=None):
         """step() on a raw device pointer to int32[N] actions (rollouts over a pre-generated [T,N] tensor)."""
         with self._guard():
             if auto_reset:
                 if self._two_level:
                     raise ValueError("auto_reset is not defined for v5/v6 (use hier_step)")
+                if epoch_slot is None:
+                    epoch, e_in, e_out = self._epoch, None, None
+                    self._epoch += 1
+                else:
+                    base, t = self._epoch_words.data_ptr(), int(epoch_slot)
+                    epoch, e_in, e_out = 0, base + 8 * (t & 1), base + 8 * ((t + 1) & 1)
                 rc = _abi.lib.lmaze_foveal_step_autoreset(self._pp, self._p_layouts, action_ptr, self._pb, self.num_envs,
-                                                          self.seed & (2 ** 64 - 1), self._epoch, self.env_base,
-                                                          None, None, self._stream())
-                self._epoch += 1
+                                                          self.seed & (2 ** 64 - 1), epoch, self.env_base,
+                                                          e_in, e_out, self._stream())
             else:
                 rc = _abi.lib.lmaze_foveal_step(self._pp, self._p_layouts, action_ptr, self._pb, self.num_envs, self._stream())
         _abi.check("lmaze_foveal_step", rc)
@@ -226,6 +231,45 @@ class LmazeFovealVecEnv(object):
             rc = _abi.lib.lmaze_v5_hier_step(self._pp, self._p_layouts, action_ptr, goal_ptr, self._pb, self.num_envs,
                                              self.seed & (2 ** 64 - 1), epoch, self.env_base, e_in, e_out, self._stream())
         _abi.check("lmaze_v5_hier_step", rc)
+
+    def rollout(self, actions, goals=None, auto_reset=False, device_epoch=False):
+        """T steps over device tensors int32[T,N], one kernel per step, no host sync: step(actions[t]) -- with the
+        reset fused in when auto_reset -- or, for v5/v6 with `goals`, the two-level step hier_step(actions[t], goals[t]).
+        device_epoch: keep the reset epoch on the device (what capture_rollout uses)."""
+        hier = goals is not None
+        for t in (actions, goals):
+            if t is not None and not (isinstance(t, torch.Tensor) and t.dtype == torch.int32 and t.dim() == 2
+                                      and t.shape[1] == self.num_envs and t.device == self.device and t.is_contiguous()):
+                raise ValueError("rollout() wants contiguous int32[T,N] tensors on %s" % (self.device,))
+        if hier and (not self._two_level or goals.shape[0] != actions.shape[0]):
+            raise ValueError("planner goals: v5/v6 only, one row per step")
+        if self._two_level and not hier:
+            if auto_reset:
+                raise ValueError("v5/v6 restart episodes through the two-level step: pass goals")
+        base, stride = actions.data_ptr(), self.num_envs * 4
+        for t in range(int(actions.shape[0])):
+            slot = t if device_epoch else None
+            if hier:
+                self.hier_step_raw(base + t * stride, goals.data_ptr() + t * stride, slot)
+            else:
+                self.step_raw(base + t * stride, auto_reset=auto_reset, epoch_slot=slot if auto_reset else None)
+        return self.obs, self.reward, self.done
+
+    def capture_rollout(self, actions, goals=None, auto_reset=False):
+        """rollout(actions, goals, auto_reset) captured into ONE hipGraph (a RolloutGraph; call .replay()): for
+        launch-bound batch sizes.  With resets in it (auto_reset, or the two-level step) the epoch is a device word
+        the launches hand on to each other, so every replay draws fresh placements -- exactly those the same steps
+        launched eagerly would draw."""
+        from .vec_env import RolloutGraph
+        needs_epoch = bool(auto_reset) or goals is not None
+        side = torch.cuda.Stream(device=self.device)
+        side.wait_stream(torch.cuda.current_stream(self.device))
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.stream(side):
+            with torch.cuda.graph(graph, stream=side):
+                self.rollout(actions, goals=goals, auto_reset=auto_reset, device_epoch=needs_epoch)
+        torch.cuda.current_stream(self.device).wait_stream(side)
+        return RolloutGraph(self, graph, int(actions.shape[0]), needs_epoch)
 
     # launch policies autotune() tries: LmazeFovealParams.launch_hint = (envs-per-workgroup code << 4) | workgroups per CU
     CANDIDATES = (0x00, 0x30, 0x34, 0x35, 0x36, 0x43, 0x44, 0x45, 0x40)

@@ -653,3 +653,31 @@ def test_foveal_autotune_picks_a_hint_and_leaves_no_trace(variant):
     assert (_bits(_np(tuned.obs)) == _bits(_np(plain.obs))).all()
     if tuned.visit is not None:
         assert (_bits(_np(tuned.visit)) == _bits(_np(plain.visit))).all()
+
+
+@pytest.mark.parametrize("variant", ["v2", "v4", "v6"])
+def test_foveal_capture_rollout_replays_equal_eager_rollouts(variant):
+    """LmazeFovealVecEnv.capture_rollout: T steps (fused reset / two-level step) as one hipGraph; two replays equal the
+    same rollouts launched eagerly, placements included (device-resident epoch)."""
+    N, T = 5000, 30
+    cap, eager = PKG.LmazeFovealVecEnv(N, variant=variant, seed=23), PKG.LmazeFovealVecEnv(N, variant=variant, seed=23)
+    gen = torch.Generator(device="cuda").manual_seed(3)
+    two = variant == "v6"
+    acts = torch.randint(0, 4 if two else 25, (T, N), dtype=torch.int32, device="cuda", generator=gen)
+    goals = torch.randint(0, 25, (T, N), dtype=torch.int32, device="cuda", generator=gen) if two else None
+    for e in (cap, eager):
+        if two:
+            e.foveal_done.fill_(True)
+        e.set_state(step_count=torch.full((N,), 40 if not two else 0, dtype=torch.int32))   # episodes end inside the rollout
+    g = cap.capture_rollout(acts, goals=goals, auto_reset=not two)
+    for rep in range(2):
+        g.replay()
+        eager.rollout(acts, goals=goals, auto_reset=not two)
+        torch.cuda.synchronize()
+        hc, he = cap.host_state(), eager.host_state()
+        for k in hc:
+            assert (hc[k].view(np.uint8) == he[k].view(np.uint8)).all(), (k, rep)
+        assert (_bits(_np(cap.obs)) == _bits(_np(eager.obs))).all() and cap._epoch == eager._epoch
+        if cap.visit is not None:
+            assert (_bits(_np(cap.visit)) == _bits(_np(eager.visit))).all()
+    assert int(_np(eager.step_count).min()) < 40 or two        # resets happened
