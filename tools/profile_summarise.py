@@ -56,7 +56,7 @@ for w in KERNEL:
                "frac_of_8TBs_from_stats_avg": N * B / (avg_us * 1e-6) / 8e12, "frac_reported_by_bench_same_process": b["roofline"]["frac"],
                "launch_hint": b["config"]["launch_hint"],
                "note": "every profiled launch of this kernel runs the policy of the timed region (no autotune in the process); "
-                       "the --stats average also covers the warm-up launches (150 + --warmup), the bench events only the timed ones"}
+                       "the device is warmed with a different kernel (400 fill-probe launches), so the --stats average covers --warmup + --steps warm launches of this kernel, the bench events the --steps timed ones"}
         # timed region from the trace: the last `steps` launches of the kernel
         tr = glob.glob(os.path.join(src, "stats_" + w, "**", "*kernel_trace.csv"), recursive=True)
         if tr:
