@@ -271,6 +271,9 @@ def parse_args(argv=None):
     ap.add_argument("--launch-hint", type=int, default=None,
                     help="fixed launch_hint (LmazeParams / LmazeFovealParams), skipping the autotune; used for the "
                          "rocprofv3 passes so that every profiled launch runs the policy the bench line was measured with")
+    ap.add_argument("--placement-trials", type=int, default=6,
+                    help="autotune: observation buffers tried (the fastest placement is kept, the others freed; 1 = keep "
+                         "the first allocation)")
     ap.add_argument("--graph", action="store_true",
                     help="capture the K timed launches into one hipGraph and time its replay (launch-bound sizes)")
     ap.add_argument("--action-rows", type=int, default=None,
@@ -392,7 +395,7 @@ def main():
         if args.launch_hint is None and not args.no_autotune:
             # untimed, state restored: (envs per workgroup, workgroups per CU) for this device, on the tensors the timed
             # steps read -- as LmazeVecEnv.autotune() does for the grid workloads
-            tuned = env.autotune(actions, goals=goals, auto_reset=args.auto_reset)
+            tuned = env.autotune(actions, goals=goals, auto_reset=args.auto_reset, placement_trials=args.placement_trials)
     else:
         if args.workload == "c2":
             layout = pkg.layouts.to_codes(pkg.layouts.GRID_8_BORDERED)   # lmaze_env.py:28-35 literal, bordered
@@ -417,7 +420,7 @@ def main():
         if args.launch_hint is None and not args.no_autotune:
             # untimed: picks (workgroups per CU, chunks per workgroup) for this shape and device, on the very
             # action tensor the timed steps read (cache-resident or not decides the ranking)
-            tuned = env.autotune(auto_reset=args.auto_reset, actions=actions)
+            tuned = env.autotune(auto_reset=args.auto_reset, actions=actions, placement_trials=args.placement_trials)
         else:
             # no autotune, so nothing has warmed the device yet: the first ~100 launches of a process run 10-40 % slow
             # (clocks still ramping) and --warmup alone would leave them in the timed region.  Warm
@@ -559,6 +562,7 @@ def main():
                        if dist is not None else None,
                        "launch_hint": int(env.params.launch_hint),
                        "perenv_kernel": perenv_kernel,
+                       "obs_placement": getattr(env, "placement", None),
                        "autotune_ms": {("%dx%d" % k if isinstance(k, tuple) else ("0x%02x" % k if foveal else str(k))): round(v, 5)
                                        for k, v in (tuned or {}).items()}},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",

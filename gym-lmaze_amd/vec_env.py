@@ -86,6 +86,7 @@ class LmazeVecEnv(object):
         self._epoch = 0
         self._epoch_words = None        # device-resident epoch pair, allocated by the first captured rollout
         self.tuned_policy = None        # (per_cu, chunks) once autotune() or the online tuner has chosen
+        self.placement = None           # autotune(placement_trials=K): where the observation buffer ended up
         self._is_v3 = variant == "v3"
 
         N = self.num_envs
@@ -290,7 +291,8 @@ class LmazeVecEnv(object):
         """LmazeParams.launch_hint for `per_cu` workgroups per CU and `chunks` chunks per workgroup."""
         return (int(per_cu) & 15) | ((int(chunks) & 15) << 4)
 
-    def autotune(self, auto_reset=False, actions=None, steps=24, candidates=None, warm=150, between=None, rounds=3):
+    def autotune(self, auto_reset=False, actions=None, steps=24, candidates=None, warm=150, between=None, rounds=3,
+                 placement_trials=0):
         """Pick the launch policy (LmazeParams.launch_hint: workgroups per CU, chunks per workgroup) by
         timing real steps with HIP events; the state is snapshotted and restored, so results are unaffected.
         The optimum is narrow and depends on shape, device and -- most of all -- on WHERE THE INPUTS COME
@@ -309,6 +311,13 @@ class LmazeVecEnv(object):
         default (3, 2) is kept unless another pair beats it by more than 1.5 %: with the minimum of two short passes
         (round 1) a pair that is fast in a burst and slower sustained could win -- (4, 1) measured 82.6 us while
         tuning and 88.6 us over the 300 timed steps that followed, next to 83.4 for the default.
+        placement_trials=K (K > 1): before the policies are timed, K - 1 further observation buffers are allocated and
+        the step is timed on each with the (5, 2) policy; the fastest buffer becomes `self.obs` (re-read the attribute:
+        it may be a NEW tensor), the others are freed.  Where the driver placed the 500-MB write target decides whether
+        policies with more than 3 workgroups per CU run at 82 or at 100 us (tools/placement_study3.py: 3 of 10
+        allocations of one process were fast ones; swapping only the obs pointer of a fast and a slow env swaps their
+        times) -- presumably the size of the physical fragments behind it, i.e. the TLB reach of thousands of
+        concurrent 31-KiB write streams.  `self.placement` records the trial times.
         Returns {(per_cu, chunks): ms per step}.  Only the shared-layout kernel has these knobs."""
         obs_bytes = self.num_envs * self.grid * self.grid * 4
         if self.layout_mode != _abi.LAYOUT_SHARED or obs_bytes <= (192 << 20):
@@ -329,6 +338,29 @@ class LmazeVecEnv(object):
             for _ in range(int(warm)):
                 self._launch_step(base + (t % R) * stride, self._p_obs, auto_reset)
                 t += 1
+            if int(placement_trials) > 1:
+                bufs = [self.obs] + [torch.empty_like(self.obs) for _ in range(int(placement_trials) - 1)]
+                self.params.launch_hint = self.launch_hint_of(5, 2)      # the policy that tells the placements apart
+                ms_of = []
+                for b in bufs:
+                    ptr = b.data_ptr()
+                    for _ in range(3):
+                        self._launch_step(base + (t % R) * stride, ptr, auto_reset)
+                        t += 1
+                    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    e0.record()
+                    for _ in range(12):
+                        self._launch_step(base + (t % R) * stride, ptr, auto_reset)
+                        t += 1
+                    e1.record()
+                    e1.synchronize()
+                    ms_of.append(e0.elapsed_time(e1) / 12)
+                keep = min(range(len(bufs)), key=lambda i: ms_of[i])
+                self.placement = {"trials_ms": [round(m, 5) for m in ms_of], "kept": keep}
+                self.obs = bufs[keep]
+                self._p_obs = self.obs.data_ptr()
+                self._expanded = None
+                del bufs
             for _round in range(int(rounds)):          # interleaved passes; the median of a candidate's passes counts
                 for c in cands:
                     self.params.launch_hint = self.launch_hint_of(*c)

@@ -634,7 +634,8 @@ def test_foveal_autotune_picks_a_hint_and_leaves_no_trace(variant):
     for e in (tuned, plain):
         if variant == "v5":
             e.foveal_done.fill_(True)
-    ms = tuned.autotune(acts, goals=goals, steps=4, warm=10)
+    ms = tuned.autotune(acts, goals=goals, steps=4, warm=10, placement_trials=3)
+    assert len(tuned.placement["trials_ms"]) == 3 and tuned.bufs.obs == tuned.obs.data_ptr()
     assert set(ms) == set(tuned.CANDIDATES) and all(v > 0 for v in ms.values())
     best = min(ms, key=ms.get)
     # the fastest hint, or the library default when nothing beats it by more than 1.5 %

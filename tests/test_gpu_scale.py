@@ -183,6 +183,25 @@ def test_autotune_keeps_results_and_state():
         assert (env.obs == ref.obs).all() and (env._state == ref._state).all(), hint
 
 
+def test_autotune_placement_trials_rehome_the_observation_buffer_only():
+    """autotune(placement_trials=K) may move env.obs to another allocation (the fastest of K); state, epoch and the
+    planes are what they were, and the rollout afterwards equals that of an env that never tuned."""
+    N, G = 1 << 19, 11
+    lay = L.to_codes(L.open_room(G, (5, 5)))
+    env = PKG.LmazeVecEnv(N, variant="v0", layout=lay, seed=6)
+    ref = PKG.LmazeVecEnv(N, variant="v0", layout=lay, seed=6)
+    acts = torch.randint(0, 4, (6, N), dtype=torch.int32, device="cuda")
+    env.step(acts[0]); ref.step(acts[0])
+    t = env.autotune(actions=acts, steps=4, warm=8, rounds=1, placement_trials=3)
+    assert len(env.placement["trials_ms"]) == 3 and 0 <= env.placement["kept"] < 3 and set(t) == set(env.CANDIDATES)
+    assert env._p_obs == env.obs.data_ptr() and (env.obs == ref.obs).all() and (env._state == ref._state).all()
+    for k in range(1, 6):
+        o1, _, _, _ = env.step(acts[k], auto_reset=True)
+        o2, _, _, _ = ref.step(acts[k], auto_reset=True)
+        assert o1.data_ptr() == env.obs.data_ptr() and (o1 == o2).all() and (env._state == ref._state).all(), k
+    assert (env.expanded()[:64] == ref.expanded()[:64]).all()
+
+
 def test_episode_stats_match_numpy():
     N, G = 100003, 11
     lay = L.to_codes(L.open_room(G, (5, 5)))
