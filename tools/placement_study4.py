@@ -16,7 +16,7 @@ for variant in (sys.argv[1:] or ["v2", "v1"]):
     hi = 4 if variant in ("v1", "v5") else 25
     ring = torch.randint(0, hi, (R, N), dtype=torch.int32, device="cuda")
     envs, pads = [], []
-    for i in range(8):
+    for i in range(8 if variant != "v4" else 6):
         e = pkg.LmazeFovealVecEnv(N, variant=variant, seed=1)
         if variant == "v1":
             e.set_foveal_goal(torch.randint(0, 5, (N, 2), dtype=torch.int32, device="cuda"))
@@ -47,6 +47,12 @@ for variant in (sys.argv[1:] or ["v2", "v1"]):
     ea.bufs.obs, eb.bufs.obs = pb, pa
     cross = {"fastest env %d with the obs of the slowest %d" % (a, b): timed(ea, 0x30), "slowest with the obs of the fastest": timed(eb, 0x30)}
     ea.bufs.obs, eb.bufs.obs = pa, pb
+    if envs[0].visit is not None:        # v4: the visit maps are a second, larger stream (read + write)
+        va, vb = ea.bufs.visit, eb.bufs.visit
+        ea.bufs.visit, eb.bufs.visit = vb, va
+        cross["fastest env with the VISIT maps of the slowest"] = timed(ea, 0x30)
+        cross["slowest with the visit maps of the fastest"] = timed(eb, 0x30)
+        ea.bufs.visit, eb.bufs.visit = va, vb
     print(json.dumps({"variant": variant, "rows": rows, "cross": cross}), flush=True)
     del envs, pads, ring
     torch.cuda.empty_cache()
