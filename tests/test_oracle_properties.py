@@ -68,3 +68,50 @@ def test_expanded_render_is_exact_replication(G, E, C, seed):
     out = O.render_expanded(obs, G, E, masks)
     want = np.stack([np.repeat(np.repeat(((obs & m) != 0).astype(np.float32), E, axis=1), E, axis=2) for m in masks], axis=1)
     assert out.shape == want.shape and (out == want).all()
+
+
+def _v5_state(n, seed):
+    import importlib
+    L = importlib.import_module("gym-lmaze_amd.layouts")
+    layouts = np.ascontiguousarray(np.stack([L.to_codes(t) for t in L.FOVEAL_GRIDS_18]))
+    p = O.foveal_params(O.VARIANT_V5, 18, 5)
+    st_ = O.FovealState(O.VARIANT_V5, n, 18)
+    O.v5_reset(p, layouts, None, 1, seed, 0, st_)
+    st_.foveal_done[:] = 1
+    return p, layouts, st_
+
+
+@settings(max_examples=12, deadline=None)
+@given(n=st.integers(1, 60), seed=st.integers(0, 10 ** 6), steps=st.integers(1, 40))
+def test_v5_two_level_step_is_reset_then_planner_step_then_step(n, seed, steps):
+    """lmaze_oracle_v5_hier_step (what the fused HIP launch is checked against) == the three pinned oracle functions
+    called one after the other with the masks the two-level loop uses, on every array of the state."""
+    rs = np.random.RandomState(seed)
+    p, layouts, a = _v5_state(n, seed)
+    _, _, b = _v5_state(n, seed)
+    for t in range(steps):
+        act = rs.randint(-1, 6, n).astype(np.int32)
+        goal = rs.randint(-2, 28, n).astype(np.int32)
+        O.v5_hier_step(p, layouts, act, goal, seed, 1 + t, a, env_base=5)
+        m_reset = (b.done != 0).astype(np.uint8)
+        m_plan = (m_reset | (b.foveal_done != 0)).astype(np.uint8)
+        O.v5_reset(p, layouts, m_reset, 1, seed, 1 + t, b, env_base=5)
+        O.v5_planner_step(p, layouts, goal, m_plan, b)
+        O.v5_step(p, layouts, act, b)
+        for f, _ in O.FovealBuffers._fields_:
+            x, y = getattr(a, f), getattr(b, f)
+            assert (np.ascontiguousarray(x).view(np.uint8) == np.ascontiguousarray(y).view(np.uint8)).all(), (f, t)
+
+
+def test_v5_two_level_rollout_statistics():
+    """Uniform random actions and planner goals: local episodes end (mostly at their 10-step limit), global ones end
+    and restart, nobody exceeds a limit -- the regime bench.py --workload v5 measures."""
+    n, T = 4000, 120
+    rs = np.random.RandomState(1)
+    p, layouts, s = _v5_state(n, 3)
+    ld = gd = 0
+    for t in range(T):
+        O.v5_hier_step(p, layouts, rs.randint(0, 4, n).astype(np.int32), rs.randint(0, 25, n).astype(np.int32), 3, 1 + t, s)
+        ld += int(s.foveal_done.sum()); gd += int(s.done.sum())
+        assert int(s.step_count.max()) <= p.step_limit and int(s.foveal_step_count.max()) <= p.foveal_step_limit + 1
+    assert 0.08 < ld / (n * T) < 0.25 and 0 < gd < ld

@@ -24,3 +24,9 @@ def test_oracle_replays_clean_under_asan_ubsan():
                          stderr=subprocess.STDOUT, text=True, timeout=600)
     assert out.returncode == 0, out.stdout[-3000:]
     assert "passed" in out.stdout and "ERROR: AddressSanitizer" not in out.stdout and "runtime error" not in out.stdout
+    # the two-level composition (malloc'ed masks) and the statistics rollout as well
+    out = subprocess.run([sys.executable, "-m", "pytest", os.path.join(ROOT, "tests", "test_oracle_properties.py"), "-x", "-q",
+                          "-p", "no:cacheprovider", "-k", "two_level"], env=env, cwd=ROOT, stdout=subprocess.PIPE,
+                         stderr=subprocess.STDOUT, text=True, timeout=600)
+    assert out.returncode == 0, out.stdout[-3000:]
+    assert "passed" in out.stdout and "ERROR: AddressSanitizer" not in out.stdout and "runtime error" not in out.stdout
