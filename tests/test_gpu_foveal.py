@@ -682,3 +682,43 @@ def test_foveal_capture_rollout_replays_equal_eager_rollouts(variant):
         if cap.visit is not None:
             assert (_bits(_np(cap.visit)) == _bits(_np(eager.visit))).all()
     assert int(_np(eager.step_count).min()) < 40 or two        # resets happened
+
+
+def test_one_million_v5_envs_two_level_step_head_and_tail_against_the_oracle():
+    """bench.py --workload v5's size: 1 048 576 envs through 25 fused two-level steps; the first and the last 2 048 envs
+    (global indices keyed into the Philox draws via env_base) against the oracle, and size-independent invariants on
+    the whole batch."""
+    N, K, T, seed, base = 1 << 20, 2048, 25, 9, 1 << 33
+    env = PKG.LmazeFovealVecEnv(N, variant="v5", seed=seed, env_base=base)
+    env.foveal_done.fill_(True)
+    lay = _np(env.layouts)
+    p = O.foveal_params(O.VARIANT_V5, env.grid, env.n_layouts)
+    h = env.host_state()
+    mirrors = []
+    for sl in (slice(0, K), slice(N - K, N)):
+        st = O.FovealState(O.VARIANT_V5, K, env.grid)
+        for k in h:
+            getattr(st, k)[...] = h[k][sl]
+        st.visit[...] = _np(env.visit[sl]); st.obs[...] = _np(env.obs[sl]); st.obs_local[...] = _np(env.obs_local[sl])
+        mirrors.append((sl, st))
+    gen = torch.Generator(device="cuda").manual_seed(4)
+    for t in range(T):
+        a = torch.randint(0, 4, (N,), dtype=torch.int32, device="cuda", generator=gen)
+        g = torch.randint(0, 25, (N,), dtype=torch.int32, device="cuda", generator=gen)
+        epoch = env._epoch
+        env.hier_step(a, g)
+        for sl, st in mirrors:
+            O.v5_hier_step(p, lay, np.ascontiguousarray(_np(a[sl])), np.ascontiguousarray(_np(g[sl])), seed, epoch, st,
+                           env_base=base + sl.start)
+    h = env.host_state()
+    for sl, st in mirrors:
+        for k in h:
+            assert (np.ascontiguousarray(h[k][sl]).view(np.uint8) == np.ascontiguousarray(getattr(st, k)).view(np.uint8)).all(), (k, sl)
+        for x, y in ((env.visit, st.visit), (env.obs, st.obs), (env.obs_local, st.obs_local)):
+            assert (_bits(_np(x[sl])) == _bits(y)).all(), sl
+    # whole batch: nobody past a limit, every observation plane holds 0/1 except the two visit planes in [0, 1]
+    assert int(env.step_count.max()) <= 10 and int(env.foveal_step_count.max()) <= 51
+    o = env.obs
+    bits = o[:, [0, 1, 3, 4, 5]]
+    assert bool(((bits == 0) | (bits == 1)).all()) and float(o[:, [2, 6]].min()) >= 0.0 and float(o[:, [2, 6]].max()) <= 1.0
+    assert bool((env.obs_local[:, 1].sum(dim=(1, 2)) <= 1).all())          # the ball is a one-hot (or outside the frame)
