@@ -438,6 +438,18 @@ class LmazeEnv_v5(_TeleportBase):
         return (self._fov(), self._loc(), core.reward, core.foveal_reward, core.done, core.foveal_done,
                 self.fovealGoal, goal)
 
+    def hierStep(self, planner_goal, action):
+        """Batched extension (num_envs > 1; not in the reference): what the usual v5/v6 loop does per env -- reset() when
+        globalDone, plannerStep(planner_goal) when localDone or after that reset, step(action) -- as ONE launch
+        (lmaze_v5_hier_step).  Returns step()'s 8-tuple."""
+        if self._single:
+            raise ValueError("hierStep is the batched extension: construct with num_envs > 1 (a single env uses reset / plannerStep / step)")
+        core = self._core
+        core.hier_step(action, planner_goal)
+        self._host = None
+        return (self._fov(), self._loc(), core.reward, core.foveal_reward, core.done, core.foveal_done,
+                self.fovealGoal, action)
+
     def buildFovealObservation(self):
         return self._fov()
 

@@ -722,3 +722,27 @@ def test_one_million_v5_envs_two_level_step_head_and_tail_against_the_oracle():
     bits = o[:, [0, 1, 3, 4, 5]]
     assert bool(((bits == 0) | (bits == 1)).all()) and float(o[:, [2, 6]].min()) >= 0.0 and float(o[:, [2, 6]].max()) <= 1.0
     assert bool((env.obs_local[:, 1].sum(dim=(1, 2)) <= 1).all())          # the ball is a one-hot (or outside the frame)
+
+
+def test_dropin_v5_batched_hier_step_is_the_three_calls():
+    """LmazeEnv_v5(num_envs=N).hierStep(goal, action) == reset(mask=globalDone) + plannerStep(mask) + step on a twin."""
+    N = 3000
+    a_env, b_env = PKG.LmazeEnv_v5(num_envs=N, seed=3, obs_mode="compact"), PKG.LmazeEnv_v5(num_envs=N, seed=3, obs_mode="compact")
+    for e in (a_env, b_env):
+        e._core.foveal_done.fill_(True)
+    gen = torch.Generator(device="cuda").manual_seed(2)
+    for t in range(40):
+        act = torch.randint(0, 4, (N,), dtype=torch.int32, device="cuda", generator=gen)
+        goal = torch.randint(0, 25, (N,), dtype=torch.int32, device="cuda", generator=gen)
+        out = a_env.hierStep(goal, act)
+        core = b_env._core
+        m_reset = core.done.clone()
+        m_plan = m_reset | core.foveal_done
+        core.reset(mask=m_reset)
+        core.planner_step(goal, mask=m_plan)
+        ref = b_env.step(act)
+        assert len(out) == len(ref) == 8
+        for x, y in zip(out[:7], ref[:7]):
+            assert (x.view(torch.uint8) == y.view(torch.uint8)).all() if x.dtype != torch.bool else (x == y).all(), t
+    with pytest.raises(ValueError):
+        PKG.LmazeEnv_v5().hierStep(0, 0)
