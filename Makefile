@@ -1,7 +1,7 @@
 # Convenience targets; the driver uses __graft_entry__.py, bench.py and pytest directly.
 PY ?= python
 
-.PHONY: build test test-gpu bench golden clean
+.PHONY: build test test-gpu bench golden golden-check install profile clean
 
 build:            ## hipcc (gfx950) -> gym-lmaze_amd/liblmaze_hip.so ; gcc -> oracle/liblmaze_oracle.so
 	$(PY) -c "import __graft_entry__ as g; g.build()"
@@ -17,6 +17,15 @@ bench:            ## the metric: env-steps/s + HBM roofline fraction + CPU basel
 
 golden:           ## regenerate tests/golden/*.npz from the reference's own step() (needs /root/reference)
 	$(PY) oracle/gen_golden.py
+
+golden-check:     ## the committed fixtures are what the committed generator emits (byte for byte, any generator order)
+	$(PY) -m pytest tests/test_golden_provenance.py -q
+
+install:          ## as the reference: pip install -e . (builds liblmaze_hip.so, installs gym_lmaze + gym_lmaze_amd)
+	$(PY) -m pip install --no-build-isolation --no-deps -e .
+
+profile:          ## on the GPU box: re-record profiles/rNN (rocprofv3 stats + PMC passes); R=2 make profile
+	bash tools/profile_round.sh $(or $(R),2)
 
 clean:
 	$(MAKE) -C gym-lmaze_amd/csrc clean
