@@ -547,11 +547,13 @@ __device__ __forceinline__ int kth_set_bit(unsigned long long m, int k) {   // p
 // patching the ball cell's dword once the inputs have arrived, to hide the load latency behind the stores: 6.5-7.7 us
 // instead of 5.6 (one partial-line store per env costs more than the latency it hides).
 template <int VARIANT, bool DO_STEP, int EPW>
-__global__ __launch_bounds__(64) void step_shared_wave8_kernel(const StepArgs a) {
+__global__ __launch_bounds__(LMAZE_BLOCK) void step_shared_wave8_kernel(const StepArgs a) {
     constexpr bool V3 = VARIANT == LMAZE_VARIANT_V3;
     constexpr int G = 8, CELLS = 64;
-    const int lane = threadIdx.x;
-    const int64_t base = (int64_t)blockIdx.x * EPW;
+    const int lane = threadIdx.x & 63;
+    // blockDim.x / 64 autonomous waves per workgroup (no barrier, no LDS: the grouping only changes what the dispatcher sees)
+    const int64_t base = ((int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)) * EPW;
+    if (base >= a.n) return;
     const int nb = (int)min((int64_t)EPW, a.n - base);
     const bool autoreset = DO_STEP && a.auto_reset;
     if (autoreset) pass_epoch_on(a.epoch_in, a.epoch_out);
@@ -758,12 +760,18 @@ static hipError_t launch_one(const StepArgs& a, int layout_mode, hipStream_t s) 
         const bool small = a.obs == nullptr || (size_t)a.n * 64 * 4 <= kNonTemporalObsBytes;
         if (small && a.mask == nullptr && (a.launch_hint & 0x100) == 0) {
             // envs per wave: launch_hint bits 4-7 = 1: 64, 2: 32, 3: 16 (0 = default)
+            // Defaults, measured at 65 536 envs under hipGraph (us per step, two boxes): 64 envs per wave x 4 waves per
+            // workgroup -- one 256-thread workgroup per CU -- 5.35-5.53; 64 x 1 5.6-5.9; 32 x 1 / 2 / 4 5.72 / 5.72-5.87 /
+            // 5.89; 64 x 2 5.9-6.1.  Smaller batches keep single-wave workgroups so that they spread over the CUs.
             int code = (a.launch_hint >> 4) & 15;
-            if (code < 1 || code > 3) code = 2;
+            if (code < 1 || code > 3) code = a.n >= 65536 ? 1 : 2;
             const int epw = 128 >> code;
-            const int64_t blocks = (a.n + epw - 1) / epw;
+            int wpb = a.launch_hint & 15;                   // bits 0-3: waves per workgroup, 1 / 2 / 4 (0 = default)
+            if (wpb != 1 && wpb != 2 && wpb != 4) wpb = a.n >= 65536 ? 4 : 1;
+            const int64_t waves = (a.n + epw - 1) / epw;
+            const int64_t blocks = (waves + wpb - 1) / wpb;
             if (!grid_ok(blocks)) return hipErrorInvalidConfiguration;
-            const dim3 grid((unsigned)blocks), block(64);
+            const dim3 grid((unsigned)blocks), block(64 * wpb);
             if (code == 1) hipLaunchKernelGGL((step_shared_wave8_kernel<VARIANT, DO_STEP, 64>), grid, block, 0, s, a);
             else if (code == 2) hipLaunchKernelGGL((step_shared_wave8_kernel<VARIANT, DO_STEP, 32>), grid, block, 0, s, a);
             else hipLaunchKernelGGL((step_shared_wave8_kernel<VARIANT, DO_STEP, 16>), grid, block, 0, s, a);

@@ -83,7 +83,8 @@ typedef struct LmazeParams {
                             it stores the current one (1..15, 0 = default); bit 8 = keep the
                             workgroup/LDS kernel where the library would pick the wave-autonomous
                             one (8x8 shared layouts whose planes stay on-die); for that kernel
-                            bits 4-7 = envs per wave (1: 64, 2: 32, 3: 16).  Performance only,
+                            bits 4-7 = envs per wave (1: 64, 2: 32, 3: 16) and bits 0-3 = waves
+                            per workgroup (1, 2, 4).  Performance only,
                             never results (lmaze_step.hip launch_shared); other bits 0.      */
 } LmazeParams;
 

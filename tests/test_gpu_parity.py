@@ -560,7 +560,8 @@ def test_fused_autoreset_fuzz():
 #    kernel it replaces there (LmazeParams.launch_hint bit 8 keeps the latter) and against the oracle
 # ----------------------------------------------------------------------------------------
 @pytest.mark.parametrize("variant", ["v0", "v3"])
-@pytest.mark.parametrize("N,hint", [(1, 0), (63, 0x10), (64, 0x10), (65, 0x20), (130, 0x30), (3003, 0), (3003, 0x10), (3003, 0x30)])
+@pytest.mark.parametrize("N,hint", [(1, 0), (63, 0x10), (64, 0x10), (65, 0x20), (130, 0x30), (3003, 0), (3003, 0x10), (3003, 0x30),
+                                    (1, 0x24), (65, 0x12), (130, 0x34), (3003, 0x22), (3003, 0x14)])   # + 2 / 4 waves per workgroup
 def test_wave_autonomous_8x8_kernel_equals_the_lds_kernel_and_the_oracle(variant, N, hint):
     lay = bordered_random_layouts(1, 8, 41 + N)[0]
     kw = dict(variant=variant, layout=lay, seed=5, step_limit=9, env_base=3)
