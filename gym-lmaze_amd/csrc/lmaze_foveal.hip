@@ -14,6 +14,16 @@
 // HBM bytes per env-step: v1 454, v2 545, v4 3 337.
 #include "lmaze_common.h"
 
+// Timing decomposition (tools/foveal_decompose.py): a build with -DLMAZE_EXPERIMENT -- never the shipped
+// one -- reads bits 8-15 of launch_hint as switches that turn phases off (results are garbage then; only the time
+// counts): 1 no set-up, 2 plain instead of non-temporal observation stores, 4 no observation stores, 8 no phase 1,
+// 16 stores as interleaved 4-KiB pieces, 32 no visit-map phase, 64 / 128 non-temporal visit-map stores / loads.
+#ifdef LMAZE_EXPERIMENT
+#define LMAZE_XP(args, mask) ((((args).p.launch_hint >> 8) & (mask)) != 0)
+#else
+#define LMAZE_XP(args, mask) false
+#endif
+
 namespace lmaze {
 
 constexpr int FOV = LMAZE_FOVEA;
@@ -204,11 +214,9 @@ __global__ __launch_bounds__(LMAZE_BLOCK) void foveal_kernel(const FovealArgs a)
             else warmed += warm_lines(a.b.goal_xy, a.n * 8, 256) + warm_lines(a.b.layout_id, a.n * 4, 256);
         }
     }
-#ifdef LMAZE_EXPERIMENT   // timing decomposition only (tools/, never shipped): bit 8 no set-up, 10 no stores, 11 no phase 1
-    const int xp = a.p.launch_hint >> 8;
-    if (!(xp & 1))
-#endif
-    if (GT != 0) {
+    if (LMAZE_XP(a, 1)) {
+        // experiment: no set-up
+    } else if (GT != 0) {
         // Row masks by ballot, straight from global memory: a wave-iteration covers RPW whole layout rows (their
         // characters are RPW*G contiguous bytes, one per lane), four ballots give the rows' masks, and every load of
         // the workgroup -- these and the copy of the characters the transition looks cells up in -- is in flight
@@ -290,10 +298,7 @@ __global__ __launch_bounds__(LMAZE_BLOCK) void foveal_kernel(const FovealArgs a)
     __syncthreads();
 
     // ---------------- phase 1: one lane per env ----------------
-#ifdef LMAZE_EXPERIMENT
-    if (!(xp & 8))
-#endif
-    for (int le = tid; le < nb; le += LMAZE_BLOCK) {
+    for (int le = tid; le < (LMAZE_XP(a, 8) ? 0 : nb); le += LMAZE_BLOCK) {
         const int64_t e = blockbase + le;
         EnvRec r;
         r.skip = 0; r.flat = -1; r.action = -1; r.lid = 0; r.gx = r.gy = -9;
@@ -616,10 +621,7 @@ __global__ __launch_bounds__(LMAZE_BLOCK) void foveal_kernel(const FovealArgs a)
     // flight per lane) and the cells that fall in their two observation windows are kept in LDS on the way; envs
     // whose map does not change (v5/v6 without localDone) only have those 2 x 25 cells gathered, one lane per
     // window row.  Every byte of a map is read and written at most once per launch.
-#ifdef LMAZE_EXPERIMENT
-    if (!(xp & 32))
-#endif
-    if (V4 && !(V5 && MODE == FM_PLANNER)) {
+    if (V4 && !(V5 && MODE == FM_PLANNER) && !LMAZE_XP(a, 32)) {
         float* vis = a.b.visit + (size_t)blockbase * CELLS;
         const int total = nb * CELLS;
         // One cell: v <- (v + [cell in the 5x5 window at (cx, cy)]) / 2 when `add` -- float32 add + exact halving ==
@@ -673,14 +675,13 @@ __global__ __launch_bounds__(LMAZE_BLOCK) void foveal_kernel(const FovealArgs a)
                     // the few freshly reset maps of a fused step are loaded too and drop what they read (a load that
                     // waits on more than the skip / update flag does not pipeline)
                     if (MODE == FM_STEP && act[u]) {
-#ifdef LMAZE_EXPERIMENT
-                        if (xp & 128) {
+                        if (LMAZE_XP(a, 128)) {
                             typedef float v4f __attribute__((ext_vector_type(4)));
                             const v4f t = __builtin_nontemporal_load(reinterpret_cast<const v4f*>(vis) + q0 + u * LMAZE_BLOCK);
                             v[u] = make_float4(t.x, t.y, t.z, t.w);
-                        } else
-#endif
-                        v[u] = reinterpret_cast<const float4*>(vis)[q0 + u * LMAZE_BLOCK];
+                        } else {
+                            v[u] = reinterpret_cast<const float4*>(vis)[q0 + u * LMAZE_BLOCK];
+                        }
                     }
                 }
 #pragma unroll
@@ -695,14 +696,13 @@ __global__ __launch_bounds__(LMAZE_BLOCK) void foveal_kernel(const FovealArgs a)
                     }
                     const bool add = !(V5 && MODE == FM_RESET) && !nostep && !(V5 && MODE == FM_STEP && !upd);   // v5 adds no window at reset
                     update4(v[u], c0, cen[le * 4], cen[le * 4 + 1], add, le, cen[le * 4 + 2], cen[le * 4 + 3]);
-#ifdef LMAZE_EXPERIMENT
-                    if (xp & 64) {
+                    if (LMAZE_XP(a, 64)) {
                         typedef float v4f __attribute__((ext_vector_type(4)));
                         const v4f t = {v[u].x, v[u].y, v[u].z, v[u].w};
                         __builtin_nontemporal_store(t, reinterpret_cast<v4f*>(vis) + q0 + u * LMAZE_BLOCK);
-                    } else
-#endif
-                    reinterpret_cast<float4*>(vis)[q0 + u * LMAZE_BLOCK] = v[u];
+                    } else {
+                        reinterpret_cast<float4*>(vis)[q0 + u * LMAZE_BLOCK] = v[u];
+                    }
                 }
             }
         } else {
@@ -759,10 +759,9 @@ __global__ __launch_bounds__(LMAZE_BLOCK) void foveal_kernel(const FovealArgs a)
     float* obs = a.b.obs + (size_t)blockbase * PERENV;
     const int R = (V5 && MODE == FM_PLANNER) ? 0 : nb * PERENV;   // plannerStep returns only the local observation
     const int nq = some_skipped ? 0 : (R >> 2);
-#ifdef LMAZE_EXPERIMENT
-    if ((xp & 16) && !V4 && EPB == 128) {
-        // timing only: the 4-KiB pieces of 8 consecutive workgroups interleaved (piece k*8 + w of the group's
-        // 1024 envs), content from this workgroup's own bit string (garbage addresses-wise)
+    if (LMAZE_XP(a, 16) && !V4 && EPB == 128) {
+        // experiment: the 4-KiB pieces of 8 consecutive workgroups interleaved (piece k*8 + w of the group's 1024
+        // envs), content from this workgroup's own bit string (garbage addresses-wise)
         const int w = blockIdx.x & 7;
         float* gbase = a.b.obs + (size_t)(blockIdx.x >> 3) * 1024 * PERENV;
         const int npieces = 1024 * PERENV / 1024;
@@ -774,10 +773,9 @@ __global__ __launch_bounds__(LMAZE_BLOCK) void foveal_kernel(const FovealArgs a)
             v4f* dst = reinterpret_cast<v4f*>(gbase) + (size_t)(k * 8 + w) * 256 + tid;
             if (a.nt) __builtin_nontemporal_store(t, dst); else *dst = t;
         }
-    } else
-    if (!(xp & 4))
-#endif
-    for (int q = tid; q < nq; q += LMAZE_BLOCK) {
+    }
+    const int nq_run = (LMAZE_XP(a, 4) || (LMAZE_XP(a, 16) && !V4 && EPB == 128)) ? 0 : nq;
+    for (int q = tid; q < nq_run; q += LMAZE_BLOCK) {
         const int f = q << 2;
         int le = f / PERENV;
         int rem = f - le * PERENV;
@@ -817,10 +815,7 @@ __global__ __launch_bounds__(LMAZE_BLOCK) void foveal_kernel(const FovealArgs a)
     }
 
     // ---------------- phase 3b (v5/v6): the local observation float[nb*4*25], v5:356-380 ----------------
-#ifdef LMAZE_EXPERIMENT
-    if (!(xp & 4))
-#endif
-    if (V5 && MODE != FM_RESET) {
+    if (V5 && MODE != FM_RESET && !LMAZE_XP(a, 4)) {
         constexpr int PERLOC = 4 * W25;
         float* loc = a.b.obs_local + (size_t)blockbase * PERLOC;
         const int RL = nb * PERLOC;                      // 100 floats per env: a store never straddles two envs
@@ -991,9 +986,7 @@ static hipError_t launch_foveal_one(const FovealArgs& a, hipStream_t s) {
     FovealArgs b = a;
     const int C = VARIANT == LMAZE_VARIANT_V1 ? 4 : (VARIANT == LMAZE_VARIANT_V2 ? 5 : 7);
     b.nt = (size_t)a.n * C * W25 * 4 > ((size_t)192 << 20);
-#ifdef LMAZE_EXPERIMENT
-    if ((a.p.launch_hint >> 8) & 2) b.nt = 0;      // bit 9: plain stores
-#endif
+    if (LMAZE_XP(a, 2)) b.nt = 0;
     // launch_hint bits 0-3: at most that many workgroups resident per CU, by padding the dynamic LDS (160 KiB per
     // CU), as the step kernel does in its streaming regime (lmaze_step.hip launch_shared); 0 = no cap
     const int per_cu = a.p.launch_hint & 15;
