@@ -271,7 +271,7 @@ def parse_args(argv=None):
     ap.add_argument("--launch-hint", type=int, default=None,
                     help="fixed launch_hint (LmazeParams / LmazeFovealParams), skipping the autotune; used for the "
                          "rocprofv3 passes so that every profiled launch runs the policy the bench line was measured with")
-    ap.add_argument("--placement-trials", type=int, default=6,
+    ap.add_argument("--placement-trials", type=int, default=10,
                     help="autotune: observation buffers tried (the fastest placement is kept, the others freed; 1 = keep "
                          "the first allocation)")
     ap.add_argument("--graph", action="store_true",
