@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
-"""Where a foveal step launch spends its time: the experimental build (csrc compiled with -DLMAZE_EXPERIMENT into
-tools/_exp/liblmaze_hip_exp.so, selected through LMAZE_HIP_LIB) can switch off the per-workgroup set-up (bit 8 of
+"""Where a foveal step launch spends its time: the experimental build (`make -C gym-lmaze_amd/csrc experiment`: csrc
+compiled with -DLMAZE_EXPERIMENT into tools/_exp/liblmaze_hip_exp.so, selected through LMAZE_HIP_LIB) can switch off the per-workgroup set-up (bit 8 of
 launch_hint), the observation stores (bit 10) and phase 1 (bit 11).  Results are garbage in those modes; only the
 time counts.   LMAZE_HIP_LIB=tools/_exp/liblmaze_hip_exp.so python tools/foveal_decompose.py v2 v1"""
 import importlib
