@@ -34,6 +34,11 @@ __device__ __forceinline__ void store16(int4* p, const int4& v) {
     }
 }
 
+// goalCount += 1 (v0:195) as an atomic without return: a plain read-modify-write makes the wave wait for the load --
+// and with it for every load issued before, i.e. for the NEXT chunk's prefetched inputs -- whenever one of its 64 envs
+// reaches the goal (about every second wave of a random rollout).  One lane per env, so the atomicity itself is unused.
+__device__ __forceinline__ void count_goal(int32_t* p) { __hip_atomic_fetch_add(p, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+
 // One env's inputs, loaded into registers BEFORE the workgroup's LDS set-up and first barrier so
 // that the two global round trips (layout, state) overlap instead of chaining: at launch-bound
 // batch sizes (65 536 x 8x8) the kernel is nothing but that latency chain.
@@ -88,7 +93,7 @@ __device__ __forceinline__ void env_phase1(const StepArgs& a, const uint8_t* lay
         float r;
         bool dn;
         if (transition_rule<VARIANT>(a, lay[tx * G + ty], ox, oy, tx, ty, sc, r_in, g.x, g.y, bx, by, r, dn) && a.goal_count)
-            a.goal_count[e] += 1;
+            count_goal(a.goal_count + e);
         a.ball[e] = make_int2(bx, by);
         a.step_count[e] = sc;
         a.reward[e] = r;
@@ -160,14 +165,51 @@ __global__ __launch_bounds__(LMAZE_BLOCK) void step_shared_kernel(const StepArgs
         if (autoreset) warmed += warm_lines(a.done, a.n, 256);
     }
 
-    for (int i = tid; i < CELLS; i += LMAZE_BLOCK) lay[i] = a.layout[i];
-    for (int i = tid; i < PAT; i += LMAZE_BLOCK) {
-        const int c = (GT != 0 && GRP > 1) ? i % CELLS : i;
-        pat[i] = cell_bits<VARIANT>(a.layout[c]);
-    }
-    if (autoreset && tid < 64) {
-        const int cnt = wave_build_spawn_list<VARIANT>(a.layout, G, CELLS, spawn, tid);
-        if (tid == 0) spawn_count_s = cnt;
+    if (GT != 0) {
+        // Set-up with ONE global round trip: every layout byte this lane needs -- its cells for the LDS copy and the
+        // pattern, and (wave 0, fused reset) the cells it ranks for the spawn list -- is loaded into registers before
+        // the first is used.  Written as plain loops the compiler waits for each load where it is consumed: layout,
+        // pattern, spawn list chunk 1, chunk 2 = four L2 round trips in series in front of the workgroup's first
+        // barrier (two without the fused reset), about 0.5 us each with only 3 workgroups per CU to hide them.
+        constexpr int CG = (GT ? GT : 1) * (GT ? GT : 1), NL = (CG + LMAZE_BLOCK - 1) / LMAZE_BLOCK, NS = (CG + 63) / 64;
+        uint8_t cb[NL], sb[NS];
+#pragma unroll
+        for (int j = 0; j < NL; ++j) {
+            cb[j] = a.layout[min(tid + j * LMAZE_BLOCK, CG - 1)];     // unconditional (clamped): a load under a branch is
+        }                                                             // waited for where the branch ends
+        const bool ranks = autoreset && tid < 64;
+        if (autoreset) {                                              // uniform
+#pragma unroll
+            for (int j = 0; j < NS; ++j) sb[j] = a.layout[min((tid & 63) + j * 64, CG - 1)];
+        }
+#pragma unroll
+        for (int j = 0; j < NL; ++j) {
+            const int c = tid + j * LMAZE_BLOCK;
+            if (c < CG) {
+                lay[c] = cb[j];
+                const int bits = cell_bits<VARIANT>(cb[j]);
+                for (int g = 0; g < GRP; ++g) pat[g * CG + c] = bits;
+            }
+        }
+        if (ranks) {   // wave 0: the accepted spawn cells in row-major order (lmaze_common.h wave_build_spawn_list)
+            int count = 0;
+#pragma unroll
+            for (int j = 0; j < NS; ++j) {
+                const int c = tid + j * 64;
+                const bool ok = c < CG && interior(c, G) && spawn_ok<VARIANT>(sb[j]);
+                const unsigned long long m = __ballot(ok);
+                if (ok) spawn[count + __popcll(m & ((1ull << tid) - 1ull))] = (uint16_t)c;
+                count += __popcll(m);
+            }
+            if (tid == 0) spawn_count_s = count;
+        }
+    } else {
+        for (int i = tid; i < CELLS; i += LMAZE_BLOCK) lay[i] = a.layout[i];
+        for (int i = tid; i < PAT; i += LMAZE_BLOCK) pat[i] = cell_bits<VARIANT>(a.layout[i]);
+        if (autoreset && tid < 64) {
+            const int cnt = wave_build_spawn_list<VARIANT>(a.layout, G, CELLS, spawn, tid);
+            if (tid == 0) spawn_count_s = cnt;
+        }
     }
     __syncthreads();
 
@@ -364,7 +406,7 @@ __global__ __launch_bounds__(LMAZE_BLOCK) void step_perenv_kernel(const StepArgs
                 bool dn;
                 if (transition_rule<VARIANT>(a, tile[tid * CELLS + tx * G + ty], ox, oy, tx, ty, sc, r_in, g.x, g.y, bx, by,
                                              r, dn) && a.goal_count)
-                    a.goal_count[e] += 1;
+                    count_goal(a.goal_count + e);
                 a.ball[e] = make_int2(bx, by);
                 a.step_count[e] = sc;
                 a.reward[e] = r;
@@ -492,7 +534,7 @@ __global__ __launch_bounds__(LMAZE_BLOCK) void step_perenv_wave_kernel(const Ste
             const int sc = sc_in + 1;
             const bool hit = transition_rule<VARIANT>(a, c, ox, oy, tx, ty, sc, r_in, g.x, g.y, bx, by, r, dn);
             if (lane == 0) {
-                if (hit && a.goal_count) a.goal_count[e] += 1;
+                if (hit && a.goal_count) count_goal(a.goal_count + e);
                 a.ball[e] = make_int2(bx, by);
                 a.step_count[e] = sc;
                 a.reward[e] = r;
@@ -609,7 +651,7 @@ __global__ __launch_bounds__(LMAZE_BLOCK) void step_shared_wave8_kernel(const St
         const bool hit = transition_rule<VARIANT>(a, c, ox, oy, tx, ty, sc, r_in, g.x, g.y, bx, by, r, dn);
         if (live) {
             const int64_t e = base + lane;
-            if (hit && a.goal_count) a.goal_count[e] += 1;
+            if (hit && a.goal_count) count_goal(a.goal_count + e);
             a.ball[e] = make_int2(bx, by);
             a.step_count[e] = sc;
             a.reward[e] = r;
@@ -684,21 +726,38 @@ static hipError_t launch_shared(const StepArgs& a, hipStream_t s) {
     const int64_t blocks = (a.n + EPB - 1) / EPB;
     size_t lds = shared_lds_bytes(a.grid, GT != 0, EPB);
     const bool nt = a.obs != nullptr && (size_t)a.n * a.grid * a.grid * 4 > kNonTemporalObsBytes;
+    // Defaults of the streaming regime, per shape, re-measured in round 2 after the set-up went to one global round trip
+    // (tools/policy_by_shape.py, three separately allocated batches per shape, all on a placement where only one or two
+    // policies run fast -- the robust case; us per step, best / the old default (3, 2)):
+    //   v0 11x11 1M   (3,1) 80.6-81.7 / 97-98     with the fused reset (3,2) 83.1-83.2 / the same
+    //   v0 8x8 2M     (2,1) 92.5-92.8 / 104-105   fused (2,1) 95.8-96.7 / 105
+    //   v0 12x12 1M   (2,1) 105-107 / 117-118     fused (2,1) 104.5-104.7 / 116-117
+    //   v3 18x18 512K (2,1) 110.4-110.9 / 130-131 fused (2,2) 111.7-111.9 / 130-131
+    //   v0 32x32 128K (2,1) 92.3-92.7 / 100-101   fused (3,2) 100-102 (2,1: 142)
+    //   v3 11x11 1M   (8,1) 91.3-91.6 / 107       fused (8,1) 97.4-97.7 / 117
+    // (On a placement where everything runs fast, v0 11x11 (3,2) and (4,2) reach 76-80 us; LmazeVecEnv.autotune()
+    // finds that out.)  launch_hint bits 0-3 / 4-7 override workgroups per CU / chunks per workgroup.
+    int def_cu = 3, def_m = 2;
+    if (GT == 11) {
+        if (VARIANT == LMAZE_VARIANT_V3) { def_cu = 8; def_m = 1; }
+        else if (!a.auto_reset) { def_cu = 3; def_m = 1; }
+    } else if (GT == 8 || GT == 12 || GT == 14) {
+        def_cu = 2; def_m = 1;
+    } else if (GT == 18) {
+        def_cu = 2; def_m = a.auto_reset ? 2 : 1;
+    } else if (GT == 32) {
+        if (!a.auto_reset) { def_cu = 2; def_m = 1; }
+    }
     int per_cu = a.launch_hint & 15;
-    if (per_cu == 0 && nt) per_cu = 3;
+    if (per_cu == 0 && nt) per_cu = def_cu;
     if (per_cu >= 1 && per_cu < 8) {
         const size_t want = lds_for_workgroups_per_cu(per_cu);
         if (want > lds) lds = want;
     }
     // chunks per workgroup (hint bits 4-7, 0 = default): the inputs of chunk k+1 are loaded while chunk k is
-    // stored, and the per-workgroup LDS set-up is shared.  Measured at 1M x 11x11 with a fresh action row from a
-    // [300,N] tensor every step, us per step, (workgroups per CU, chunks), two boxes:
-    //   (3,1) 93 / -    (3,2) 86 / 85    (4,2) 85 / 97    (5,2) 81 / 100    (8,1) 96 / -    persistent grids 98-127
-    // (before the action row was warmed at kernel start: (3,1) 113-115, (3,2) 108, (4,2) 94, (5,2) 87-91, (8,1) 91.)
-    // The optimum is narrow and moves from device to device; (3,2) is the one that held on both, so it is
-    // the default, and LmazeVecEnv.autotune() times the candidates on the caller's own action tensor.
+    // stored, and the per-workgroup LDS set-up is shared.
     int m = (a.launch_hint >> 4) & 15;
-    if (m == 0) m = nt ? 2 : 1;
+    if (m == 0) m = nt ? def_m : 1;
     const int64_t grid = (blocks + m - 1) / m;
     if (!grid_ok(grid)) return hipErrorInvalidConfiguration;
     if (nt)

@@ -283,8 +283,8 @@ class LmazeVecEnv(object):
         _abi.check("lmaze_step_" + self.variant, rc)
 
     # launch policies autotune() tries: (workgroups per CU, chunks per workgroup) -> LmazeParams.launch_hint
-    DEFAULT_POLICY = (3, 2)       # what launch_hint = 0 means in the streaming regime (lmaze_step.hip launch_shared)
-    CANDIDATES = ((3, 1), (3, 2), (4, 1), (4, 2), (5, 2), (5, 3), (6, 2), (6, 3), (7, 2), (8, 1), (8, 2), (8, 3))
+    DEFAULT_POLICY = (0, 0)       # launch_hint = 0: the library's per-shape default (lmaze_step.hip launch_shared)
+    CANDIDATES = ((0, 0), (2, 1), (2, 2), (3, 1), (3, 2), (4, 1), (4, 2), (5, 2), (5, 3), (6, 2), (6, 3), (7, 2), (8, 1), (8, 2))
 
     @staticmethod
     def launch_hint_of(per_cu, chunks=1):
@@ -308,7 +308,8 @@ class LmazeVecEnv(object):
         own with an event pair and the median counts.  `warm` untimed launches come first: a cold device
         (the first ~100 launches of a process) ranks the candidates differently from the steady state.
         `rounds` interleaved passes over the candidates, the MEDIAN of a candidate's passes counts, and the library
-        default (3, 2) is kept unless another pair beats it by more than 1.5 %: with the minimum of two short passes
+        default (candidate (0, 0) = launch_hint 0, a per-shape pair) is kept unless another pair beats it by more than
+        1.5 %: with the minimum of two short passes
         (round 1) a pair that is fast in a burst and slower sustained could win -- (4, 1) measured 82.6 us while
         tuning and 88.6 us over the 300 timed steps that followed, next to 83.4 for the default.
         placement_trials=K (K > 1): before the policies are timed, K - 1 further observation buffers are allocated and
