@@ -60,7 +60,11 @@ __device__ __forceinline__ EnvIn load_env(const StepArgs& a, int64_t e) {
         in.act = a.action[e];
         in.sc = a.step_count[e];
         if (!V3) in.r = a.reward[e];
-        if (a.auto_reset) in.was_done = a.done[e];
+        // branch-free (a load under a branch is waited for where the branch ends, in front of whatever else is in flight):
+        // without the fused reset the lane reads byte 0 of the layout instead -- one cached address, no traffic
+        const uint8_t* dp = a.auto_reset ? a.done + e : a.layout;
+        const int dv = *dp;
+        in.was_done = a.auto_reset ? dv : 0;
     }
     return in;
 }
@@ -600,10 +604,10 @@ __global__ __launch_bounds__(LMAZE_BLOCK) void step_shared_wave8_kernel(const St
     const bool autoreset = DO_STEP && a.auto_reset;
     if (autoreset) pass_epoch_on(a.epoch_in, a.epoch_out);
     const bool live = lane < nb;
+    const int myc = a.layout[lane];                                   // cell `lane` of the layout; issued first
     EnvIn in{};
     in.b = make_int2(1, 1); in.g = make_int2(-1, -1);
     if (live) in = load_env<VARIANT, DO_STEP>(a, base + lane);
-    const int myc = a.layout[lane];                                   // cell `lane` of the layout
     const int mypat = cell_bits<VARIANT>((uint8_t)myc);
     const int p4 = (lane & 15) << 2;                                  // first cell of this lane's stores
     const int4 pat4 = make_int4(__shfl(mypat, p4, 64), __shfl(mypat, p4 + 1, 64), __shfl(mypat, p4 + 2, 64),
