@@ -395,7 +395,12 @@ static hipError_t launch_expand_stream(const ExpandArgs& a, hipStream_t s) {
     constexpr int S = GT * ET;
     const int64_t L = (int64_t)a.channels * S * S, total = a.n * L;
     ExpandArgs b = a;
-    b.chunk_floats = GT >= 32 ? 12288 : 8192;                        // 48 / 32 KiB per workgroup
+    // Round 2 (65 536 envs, two processes, TB/s; stretch x workgroups per CU, non-temporal): 11x11 x7 16 KiB x 5 6.61,
+    // 16 KiB x 6 6.35, 32 KiB x 3 (round 1's choice) 6.2; 12x12 x7 6.56-6.59 / 6.54-6.58 / 6.22; 18x18 x4 6.62 / 6.88-6.92 /
+    // 6.2-6.3; 32x32 x7 5.95 / 5.8 / 5.7 against 48 KiB x 3 6.21-6.26.  Plain stores reach 6.6-6.8 on single shapes and
+    // fall to 3.6-4.8 on others; 4- and 8-KiB stretches lose to the per-workgroup index set-up (2.0-4.5).
+    b.chunk_floats = GT >= 32 ? 12288 : 4096;                        // 48 / 16 KiB per workgroup
+    const int per_cu = GT >= 32 ? 3 : (GT == 18 ? 6 : 5);
     if (b.chunk_floats > L) b.chunk_floats = (int32_t)(L & ~(int64_t)1023);   // a stretch covers two envs at most
     if (b.chunk_floats < 1024) return launch_expand_generic(a, s);
     const int64_t chunks = (total + b.chunk_floats - 1) / b.chunk_floats;
@@ -404,7 +409,7 @@ static hipError_t launch_expand_stream(const ExpandArgs& a, hipStream_t s) {
     size_t lds = ((size_t)2 * GT * GT * 4 + LMAZE_MAX_CHANNELS * 4 + 15) & ~(size_t)15;
     const bool nt = total * 4 > ((int64_t)192 << 20);                // cannot stay in the 256 MiB Infinity Cache
     if (nt) {
-        const size_t want = expand_lds_for_workgroups_per_cu(3);
+        const size_t want = expand_lds_for_workgroups_per_cu(per_cu);
         if (want > lds) lds = want;
         hipLaunchKernelGGL((render_expanded_stream_kernel<GT, ET, true>), dim3((unsigned)chunks), dim3(LMAZE_BLOCK), lds, s, b);
     } else {
@@ -416,7 +421,8 @@ static hipError_t launch_expand_stream(const ExpandArgs& a, hipStream_t s) {
 static hipError_t launch_planes_stream(const ExpandArgs& a, hipStream_t s) {
     const int64_t cells = (int64_t)a.grid * a.grid, L = a.channels * cells, total = a.n * L;
     ExpandArgs b = a;
-    b.chunk_floats = 8192;                                           // 32 KiB per workgroup
+    b.chunk_floats = 4096;                                           // 16 KiB per workgroup (round 2: 6.14 / 6.40 TB/s at
+                                                                     // 1M x 11x11 / 256K x 32x32 against 5.93 / 6.03 with 32 KiB)
     const int64_t chunks = (total + b.chunk_floats - 1) / b.chunk_floats;
     if (cells < 4 || !grid_ok(chunks) || ((uintptr_t)a.out & 63)) return launch_expand_generic(a, s);
     b.inv_l = (((uint64_t)1 << 32) + (uint64_t)L - 1) / (uint64_t)L;

@@ -1236,14 +1236,16 @@ int lmaze_expand_planes(const float* planes, int32_t channels, int32_t g, int32_
     a.g = g;
     a.expansion = expansion;
     if (g == FOV && expansion == 7 && !((uintptr_t)out & 63)) {
-        // measured (262 144 envs, C = 4/5/7): 32 KiB x 8 per CU 5.2 TB/s; 48 KiB x 2 per CU + non-temporal 6.2-6.4
-        const int chunk = 12288;
+        // measured (262 144 envs, C = 4/5/7), round 1: 32 KiB x 8 per CU 5.2 TB/s; 48 KiB x 2 per CU + non-temporal 6.2-6.4
+        // round 2 (C = 4 / 5 / 7, TB/s): 16 KiB x 3 per CU + non-temporal 6.50 / 6.45 / 6.57, 16 KiB x 4 6.26 / 6.54 / 6.27,
+        // 48 KiB x 2 (round 1's choice) 6.48 / 6.37 / 6.23, 32 KiB x 2 6.26 / 6.26 / 6.21
+        const int chunk = 4096;
         const int64_t total = n * (int64_t)channels * (FOV * 7) * (FOV * 7);
         const int64_t chunks = (total + chunk - 1) / chunk;
         if (grid_ok(chunks)) {
             size_t lds = ((size_t)(chunk / ((FOV * 7) * (FOV * 7)) + 3) * W25 * 4 + 15) & ~(size_t)15;   // planes touched + one of slack
             if (total * 4 > ((int64_t)192 << 20)) {
-                const size_t cap = 160 * 1024, want = ((cap / 2 + cap / 3) / 2) & ~(size_t)255;      // 2 workgroups per CU
+                const size_t cap = 160 * 1024, want = ((cap / 3 + cap / 4) / 2) & ~(size_t)255;      // 3 workgroups per CU
                 if (want > lds) lds = want;
                 hipLaunchKernelGGL((expand_planes_stream_kernel<FOV, 7, true>), dim3((unsigned)chunks), dim3(LMAZE_BLOCK), lds,
                                    (hipStream_t)stream, a, chunk);
