@@ -1043,11 +1043,13 @@ static hipError_t launch_foveal_mode(const FovealArgs& a, hipStream_t s) {
     // the chunk size and the cap: the kernels sit within 3-5 % of what their write pattern -- every workgroup streaming
     // a private, env-aligned chunk -- reaches on this memory system (tools/wbench.hip: 6.1 TB/s for 32-KiB private
     // chunks against 6.9 for a fill in which consecutive workgroups write consecutive 4-KiB pieces).
-    FovealArgs h = a;
-    if (MODE == FM_STEP && a.p.variant == LMAZE_VARIANT_V1 && (a.p.launch_hint & 15) == 0 && !a.auto_reset)
-        h.p.launch_hint |= 5;
+    // After the set-up went to one barrier with ballot-built row masks (cheap enough for small workgroups), re-measured on
+    // two boxes: v1 32 envs per workgroup, uncapped 66.8-67.2 us (0.89 of peak; 64 x 4-5 per CU 71-73, 16 envs 105);
+    // v4 32 envs 589-652 against 600-675 with 64 on the same boxes; v2 and v5 stay at 64 (32: 102 / 487 against 88-92 / 441).
     switch (a.p.variant) {
-        case LMAZE_VARIANT_V1: return launch_foveal_one<LMAZE_VARIANT_V1, MODE, 64>(h, s);
+        case LMAZE_VARIANT_V1:
+            if (MODE == FM_STEP && !a.auto_reset) return launch_foveal_one<LMAZE_VARIANT_V1, MODE, 32>(a, s);
+            return launch_foveal_one<LMAZE_VARIANT_V1, MODE, 64>(a, s);
         case LMAZE_VARIANT_V2:
             if (MODE == FM_STEP && a.auto_reset) return launch_foveal_one<LMAZE_VARIANT_V2, MODE, 256>(a, s);
             return launch_foveal_one<LMAZE_VARIANT_V2, MODE, 64>(a, s);
@@ -1055,7 +1057,8 @@ static hipError_t launch_foveal_mode(const FovealArgs& a, hipStream_t s) {
         case LMAZE_VARIANT_V6:
             return launch_foveal_one<LMAZE_VARIANT_V5, MODE, 64>(a, s);
         default:
-            // 64 envs per workgroup: 83 KiB of visit maps streamed + 45 KiB of observation written
+            // 32 envs per workgroup: 41 KiB of visit maps streamed + 22 KiB of observation written
+            if (MODE == FM_STEP && !a.auto_reset) return launch_foveal_one<LMAZE_VARIANT_V4, MODE, 32>(a, s);
             return launch_foveal_one<LMAZE_VARIANT_V4, MODE, 64>(a, s);
     }
 }

@@ -273,7 +273,7 @@ class LmazeFovealVecEnv(object):
         return RolloutGraph(self, graph, int(actions.shape[0]), needs_epoch)
 
     # launch policies autotune() tries: LmazeFovealParams.launch_hint = (envs-per-workgroup code << 4) | workgroups per CU
-    CANDIDATES = (0x00, 0x30, 0x34, 0x35, 0x36, 0x43, 0x44, 0x45, 0x40)
+    CANDIDATES = (0x00, 0x20, 0x26, 0x27, 0x30, 0x34, 0x35, 0x36, 0x43, 0x40)
 
     def autotune(self, actions, goals=None, auto_reset=False, steps=24, candidates=None, warm=100, rounds=3,
                  placement_trials=0):

@@ -19,9 +19,9 @@ HOT = {   # mangled-name fragment -> minimum waves per SIMD
     "step_shared_wave8_kernelILi0ELb1ELi64E": 8,           # C2 (wave-autonomous; the workgroup kernel below is kept for large 8x8 batches)
     "step_shared_kernelILi8ELi0ELb1ELi128E": 7,
     "step_perenv_wave_kernelILi32ELi0ELb1ELb1E": 6,        # C5
-    "foveal_kernelILi1ELi0ELi64ELi14ELb0E": 6,             # v1 step
+    "foveal_kernelILi1ELi0ELi32ELi14ELb0E": 6,             # v1 step
     "foveal_kernelILi2ELi0ELi128ELi18ELb0E": 6,            # v2 step
-    "foveal_kernelILi4ELi0ELi64ELi18ELb0E": 6,             # v4 step
+    "foveal_kernelILi4ELi0ELi32ELi18ELb0E": 6,             # v4 step
     "foveal_kernelILi4ELi0ELi64ELi18ELb1E": 6,             # v4 step with the reset fused in
     "foveal_kernelILi5ELi0ELi64ELi18ELb1E": 5,             # v5/v6 two-level step (reset + plannerStep + step)
     "render_expanded_stream_kernelILi11ELi7ELb1E": 8,
