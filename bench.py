@@ -563,7 +563,7 @@ def main():
                        "launch_hint": int(env.params.launch_hint),
                        "perenv_kernel": perenv_kernel,
                        "obs_placement": getattr(env, "placement", None),
-                       "autotune_ms": {("%dx%d" % k if isinstance(k, tuple) else ("0x%02x" % k if foveal else str(k))): round(v, 5)
+                       "autotune_ms": {("x".join(str(int(x)) for x in k) if isinstance(k, tuple) else ("0x%02x" % k if foveal else str(k))): round(v, 5)
                                        for k, v in (tuned or {}).items()}},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_source,

@@ -744,7 +744,9 @@ static hipError_t launch_shared(const StepArgs& a, hipStream_t s) {
     int def_cu = 3, def_m = 2;
     if (GT == 11) {
         if (VARIANT == LMAZE_VARIANT_V3) { def_cu = 8; def_m = 1; }
-        else if (!a.auto_reset) { def_cu = 3; def_m = 1; }
+        else if (EPB == 32) { def_cu = 8; def_m = 1; }
+        else if (a.auto_reset) { def_cu = 3; def_m = 2; }
+        else { def_cu = 3; def_m = 1; }
     } else if (GT == 8 || GT == 12 || GT == 14) {
         def_cu = 2; def_m = 1;
     } else if (GT == 18) {
@@ -842,6 +844,14 @@ static hipError_t launch_one(const StepArgs& a, int layout_mode, hipStream_t s) 
         }
         return launch_shared<GT, VARIANT, DO_STEP, 128>(a, s);
     } else if constexpr (GT == 11 || GT == 12) {
+        // launch_hint bits 10-11: envs per workgroup, 1: 64, 2: 32 (0 = default).  Round 2, once the set-up was one global
+        // round trip: v0 11x11 1M, 32 envs (15 KiB of planes) per workgroup, uncapped, one chunk 76.1-76.6 us on every
+        // placement of the observation buffer tried, against 78.6-80.9 for 64 envs at (3, 2) / (3, 1) (16 envs: 90+);
+        // with the fused reset 64 envs at (3, 2) 85-86, 32 envs 84-86; (4, 1) at 64 envs 79 on one box, 95 on the next.
+        int sel = (a.launch_hint >> 10) & 3;
+        const bool streaming = a.obs != nullptr && (size_t)a.n * GT * GT * 4 > kNonTemporalObsBytes;
+        if (sel == 0) sel = (GT == 11 && VARIANT == LMAZE_VARIANT_V0 && DO_STEP && !a.auto_reset && streaming) ? 2 : 1;
+        if (sel == 2) return launch_shared<GT, VARIANT, DO_STEP, 32>(a, s);
         return launch_shared<GT, VARIANT, DO_STEP, 64>(a, s);
     } else if constexpr (GT == 14 || GT == 18) {
         return launch_shared<GT, VARIANT, DO_STEP, 32>(a, s);

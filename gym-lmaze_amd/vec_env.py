@@ -284,12 +284,15 @@ class LmazeVecEnv(object):
 
     # launch policies autotune() tries: (workgroups per CU, chunks per workgroup) -> LmazeParams.launch_hint
     DEFAULT_POLICY = (0, 0)       # launch_hint = 0: the library's per-shape default (lmaze_step.hip launch_shared)
-    CANDIDATES = ((0, 0), (2, 1), (2, 2), (3, 1), (3, 2), (4, 1), (4, 2), (5, 2), (5, 3), (6, 2), (6, 3), (7, 2), (8, 1), (8, 2))
+    # a third element selects the envs per workgroup where the kernel offers a choice (11x11, 12x12: 1 = 64, 2 = 32)
+    CANDIDATES = ((0, 0), (2, 1), (2, 2), (3, 1), (3, 2), (4, 1), (4, 2), (5, 2), (6, 2), (7, 2), (8, 1), (8, 2),
+                  (6, 1, 2), (8, 1, 2), (5, 1, 2), (4, 2, 2), (4, 1, 1), (3, 2, 1))
 
     @staticmethod
-    def launch_hint_of(per_cu, chunks=1):
-        """LmazeParams.launch_hint for `per_cu` workgroups per CU and `chunks` chunks per workgroup."""
-        return (int(per_cu) & 15) | ((int(chunks) & 15) << 4)
+    def launch_hint_of(per_cu, chunks=1, epb_sel=0):
+        """LmazeParams.launch_hint for `per_cu` workgroups per CU, `chunks` chunks per workgroup and, where the kernel
+        offers the choice, the envs-per-workgroup selector (include/lmaze.h: bits 10-11)."""
+        return (int(per_cu) & 15) | ((int(chunks) & 15) << 4) | ((int(epb_sel) & 3) << 10)
 
     def autotune(self, auto_reset=False, actions=None, steps=24, candidates=None, warm=150, between=None, rounds=3,
                  placement_trials=0):
@@ -324,6 +327,8 @@ class LmazeVecEnv(object):
         if self.layout_mode != _abi.LAYOUT_SHARED or obs_bytes <= (192 << 20):
             return {}       # the knobs only pay in the streaming (non-temporal store) regime
         cands = [tuple(c) if isinstance(c, (tuple, list)) else (int(c), 1) for c in (candidates or self.CANDIDATES)]
+        if self.grid not in (11, 12):
+            cands = [c for c in cands if len(c) < 3]          # the selector only exists for those two sizes
         N = self.num_envs
         if actions is None:
             rows = max(2, min(512, (320 << 20) // (4 * N) + 1))          # > 256 MiB of action rows

@@ -15,7 +15,8 @@ CSRC = os.path.join(ROOT, "gym-lmaze_amd", "csrc")
 HIPCC = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
 
 HOT = {   # mangled-name fragment -> minimum waves per SIMD
-    "step_shared_kernelILi11ELi0ELb1ELi64ELb1E": 7,        # C3, the metric (launched at 3 workgroups = 12 waves per CU)
+    "step_shared_kernelILi11ELi0ELb1ELi32ELb1E": 7,        # C3, the metric (32 envs per workgroup, uncapped)
+    "step_shared_kernelILi11ELi0ELb1ELi64ELb1E": 7,        # C3 with the fused reset (64 envs, 4 workgroups per CU)
     "step_shared_wave8_kernelILi0ELb1ELi64E": 8,           # C2 (wave-autonomous; the workgroup kernel below is kept for large 8x8 batches)
     "step_shared_kernelILi8ELi0ELb1ELi128E": 7,
     "step_perenv_wave_kernelILi32ELi0ELb1ELb1E": 6,        # C5

@@ -15,7 +15,7 @@ src, rnd = sys.argv[1], int(sys.argv[2])
 dst = os.path.join(src, "keep")
 os.makedirs(dst, exist_ok=True)
 
-KERNEL = {"c3": "step_shared_kernel<11, 0, true, 64, true>", "c2": "step_shared_wave8_kernel<0, true, ",
+KERNEL = {"c3": "step_shared_kernel<11, 0, true, ", "c2": "step_shared_wave8_kernel<0, true, ",
           "c5": "step_perenv_wave_kernel<32, 0, true, true>", "v1": "foveal_kernel<1, 0, ",
           "v2": "foveal_kernel<2, 0, ", "v4": "foveal_kernel<4, 0, ", "v5": "foveal_kernel<5, 0, "}   # envs per workgroup: tuned
 KEY = {"c3": "g11_shared", "c5": "g32_perenv", "c2": "g8_shared"}

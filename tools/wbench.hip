@@ -24,6 +24,7 @@ __device__ __forceinline__ void st16(float* p, size_t q, v4f v) {
 
 // MODE 0: the workgroup stripes its chunk, 4 KiB per iteration (the step kernels' schedule)
 // MODE 1: each wave owns a contiguous quarter of the chunk, 1 KiB per iteration
+// MODE 3: MODE 0, but workgroup b starts at iteration (b * grp) mod iterations of its chunk and wraps
 // MODE 2: chunk interleaved over a group of `grp` workgroups: workgroup w of the group writes the 4-KiB pieces
 //         w, w + grp, w + 2 grp ... of the group's grp*chunk bytes (the group's front stays compact)
 // pace: s_sleep between two stores of a lane
@@ -39,6 +40,16 @@ __global__ __launch_bounds__(256) void chunk_kernel(float* dst, int chunk16, siz
         for (int q = tid; q < chunk16 && base + q < n16; q += 256) {
             st16<NT>(dst, base + q, v);
             if (pace) __builtin_amdgcn_s_sleep(1);
+        }
+    } else if (MODE == 3) {                                                  // MODE 0 with the start rotated per workgroup (grp = multiplier)
+        const size_t base = (size_t)blockIdx.x * chunk16;
+        const int iters = (chunk16 + 255) >> 8;
+        const int rot = (int)((blockIdx.x * (unsigned)grp) % (unsigned)iters);
+        for (int it = 0; it < iters; ++it) {
+            int k = it + rot;
+            if (k >= iters) k -= iters;
+            const int q = k * 256 + tid;
+            if (q < chunk16 && base + q < n16) st16<NT>(dst, base + q, v);
         }
     } else if (MODE == 1) {
         const int per_wave = chunk16 >> 2;
@@ -71,6 +82,7 @@ static size_t lds_for_per_cu(int k) {
 
 int main(int argc, char** argv) {
     const int rounds = argc > 1 ? atoi(argv[1]) : 7, iters = argc > 2 ? atoi(argv[2]) : 20;
+    const bool only_rot = argc > 3 && std::string(argv[3]) == "rotate";      // the chunk-size x rotation study only
     const size_t bytes = (size_t)(1 << 20) * 500, n16 = bytes / 16;
     float* d;
     int* dep;
@@ -92,14 +104,26 @@ int main(int argc, char** argv) {
                              else hipLaunchKernelGGL((chunk_kernel<false, 0>), dim3(blocks), dim3(256), lds, st, d, chunk16, n16, grp, pace, dp); }
             else if (mode == 1) { if (nt) hipLaunchKernelGGL((chunk_kernel<true, 1>), dim3(blocks), dim3(256), lds, st, d, chunk16, n16, grp, pace, dp);
                                   else hipLaunchKernelGGL((chunk_kernel<false, 1>), dim3(blocks), dim3(256), lds, st, d, chunk16, n16, grp, pace, dp); }
+            else if (mode == 3) { if (nt) hipLaunchKernelGGL((chunk_kernel<true, 3>), dim3(blocks), dim3(256), lds, st, d, chunk16, n16, grp, pace, dp);
+                                  else hipLaunchKernelGGL((chunk_kernel<false, 3>), dim3(blocks), dim3(256), lds, st, d, chunk16, n16, grp, pace, dp); }
             else { if (nt) hipLaunchKernelGGL((chunk_kernel<true, 2>), dim3(blocks), dim3(256), lds, st, d, chunk16, n16, grp, pace, dp);
                    else hipLaunchKernelGGL((chunk_kernel<false, 2>), dim3(blocks), dim3(256), lds, st, d, chunk16, n16, grp, pace, dp); }
         }, {}});
     };
     for (int nt = 0; nt < 2; ++nt) {
         add("stripe", 0, nt, 4096, 0, 1, 0, false);                 // one store per thread: the fill
+        if (!only_rot)
         for (int cb : {8192, 16384, 32768, 65536})
             for (int cu : {0, 3, 5}) add("stripe", 0, nt, cb, cu, 1, 0, false);
+        if (only_rot) {
+            for (int cb : {15488, 16384, 18432, 30976, 32768, 36864, 16000, 32000, 12800, 25600}) {
+                add("stripe", 0, nt, cb, 0, 1, 0, false);
+                add("stripe", 0, nt, cb, 3, 1, 0, false);
+                for (int mul : {1, 3, 5}) add("rotate", 3, nt, cb, 0, mul, 0, false);
+                add("rotate", 3, nt, cb, 3, 1, 0, false);
+            }
+            continue;
+        }
         add("wave-own", 1, nt, 32768, 0, 1, 0, false);
         add("wave-own", 1, nt, 32768, 3, 1, 0, false);
         for (int grp : {8, 64, 256}) add("interleave", 2, nt, 32768, 0, grp, 0, false);
