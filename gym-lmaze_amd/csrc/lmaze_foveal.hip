@@ -197,8 +197,13 @@ __global__ __launch_bounds__(LMAZE_BLOCK) void foveal_kernel(const FovealArgs a)
     __shared__ int any_skip;
 
     const int tid = threadIdx.x;
-    const int64_t blockbase = (int64_t)blockIdx.x * EPB;
-    const int nb = (int)min((int64_t)EPB, a.n - blockbase);
+    // A workgroup takes chunks of EPB envs grid-stride (chunk = blockIdx.x, + gridDim.x, ...; one chunk each unless the
+    // launcher asked for more): the set-up below -- row masks of all L layouts -- is paid once per workgroup while the
+    // private range it streams at any moment stays one small chunk (lmaze_step.hip step_shared_kernel does the same)
+    const int64_t nchunks = (a.n + EPB - 1) / EPB;
+    int64_t chunk = blockIdx.x;
+    int64_t blockbase = chunk * EPB;
+    int nb = (int)min((int64_t)EPB, a.n - blockbase);
     if (tid == 0) any_skip = 0;
     for (int i = tid; i < EPB * 12; i += LMAZE_BLOCK) obits[i] = 0u;       // obits and lbits
     if (MODE == FM_STEP && AR) pass_epoch_on(a.epoch_in, a.epoch_out);
@@ -297,6 +302,7 @@ __global__ __launch_bounds__(LMAZE_BLOCK) void foveal_kernel(const FovealArgs a)
     }
     __syncthreads();
 
+  for (;;) {
     // ---------------- phase 1: one lane per env ----------------
     for (int le = tid; le < (LMAZE_XP(a, 8) ? 0 : nb); le += LMAZE_BLOCK) {
         const int64_t e = blockbase + le;
@@ -828,6 +834,15 @@ __global__ __launch_bounds__(LMAZE_BLOCK) void foveal_kernel(const FovealArgs a)
             reinterpret_cast<float4*>(loc)[q] = make_float4(v[0], v[1], v[2], v[3]);
         }
     }
+    chunk += gridDim.x;
+    if (chunk >= nchunks) break;                                           // uniform over the workgroup
+    blockbase = chunk * EPB;
+    nb = (int)min((int64_t)EPB, a.n - blockbase);
+    __syncthreads();                                                       // every wave is done with this chunk's strings and flags
+    for (int i = tid; i < EPB * 12; i += LMAZE_BLOCK) obits[i] = 0u;
+    if (tid == 0) any_skip = 0;
+    __syncthreads();
+  }
     if (warmed == 0x7fedcba9 && a.n < 0) a.b.done[0] = 1;   // never true: keeps the warming loads alive
 }
 
@@ -974,6 +989,8 @@ __global__ __launch_bounds__(LMAZE_BLOCK) void expand_planes_stream_kernel(const
 // ------------------------------------------------------------------------------------
 // host side
 // ------------------------------------------------------------------------------------
+constexpr size_t kFovealStreamBytes = (size_t)192 << 20;   // observations larger than this are streamed (non-temporal stores)
+
 template <int VARIANT, int MODE, int EPB>
 static hipError_t launch_foveal_one(const FovealArgs& a, hipStream_t s) {
     const int cells = a.p.grid * a.p.grid;
@@ -981,11 +998,14 @@ static hipError_t launch_foveal_one(const FovealArgs& a, hipStream_t s) {
     // obs bit string 32 B + obs_local bit string 16 B + centres 8 B + flags 4 B + reset centre 4 B per env, row masks, layout characters, visit samples
     size_t lds = (size_t)EPB * 64 + (3 * (size_t)L * a.p.grid + 2 * (size_t)a.p.grid) * 8 + (size_t)((L * cells + 15) & ~15);
     if (VARIANT == LMAZE_VARIANT_V4 || VARIANT == LMAZE_VARIANT_V5) lds += (size_t)EPB * 2 * W25 * 4;
-    const int64_t blocks = (a.n + EPB - 1) / EPB;
+    // launch_hint bits 8-9 (plain and fused step): chunks of EPB envs per workgroup - 1 (more than 4, or 16-env chunks: slower)
+    const int64_t nchunks = (a.n + EPB - 1) / EPB;
+    const int m = MODE == FM_STEP ? ((a.p.launch_hint >> 8) & 3) + 1 : 1;
+    const int64_t blocks = (nchunks + m - 1) / m;
     if (!grid_ok(blocks)) return hipErrorInvalidConfiguration;
     FovealArgs b = a;
     const int C = VARIANT == LMAZE_VARIANT_V1 ? 4 : (VARIANT == LMAZE_VARIANT_V2 ? 5 : 7);
-    b.nt = (size_t)a.n * C * W25 * 4 > ((size_t)192 << 20);
+    b.nt = (size_t)a.n * C * W25 * 4 > kFovealStreamBytes;
     if (LMAZE_XP(a, 2)) b.nt = 0;
     // launch_hint bits 0-3: at most that many workgroups resident per CU, by padding the dynamic LDS (160 KiB per
     // CU), as the step kernel does in its streaming regime (lmaze_step.hip launch_shared); 0 = no cap
@@ -1024,8 +1044,22 @@ static bool launch_step_hinted(const FovealArgs& a, hipStream_t s, hipError_t& r
 }
 
 template <int MODE>
-static hipError_t launch_foveal_mode(const FovealArgs& a, hipStream_t s) {
-    if (a.n == 0) return hipSuccess;
+static hipError_t launch_foveal_mode(const FovealArgs& a0, hipStream_t s) {
+    if (a0.n == 0) return hipSuccess;
+    FovealArgs a = a0;
+    if (MODE == FM_STEP && a.p.launch_hint == 0 && !a.auto_reset) {
+        // Default policy of the plain step in the streaming regime (observation larger than the Infinity Cache), as a
+        // hint.  Round 2, after workgroups learnt to take several chunks: on a box where every uncapped one-chunk launch of
+        // v1 sat at 78.5 us whatever the envs per workgroup (on other boxes 32 envs: 66.8-67.4), 32 envs x 3 chunks ran
+        // at 68.0 and x 2 at 68.7; v4 32 x 2 595 against 611; v2 64 envs at 5 workgroups per CU 88.7-89.1 on two
+        // boxes against 92-96 uncapped (32 x 2-3: 93-94).
+        const int C = a.p.variant == LMAZE_VARIANT_V1 ? 4 : (a.p.variant == LMAZE_VARIANT_V2 ? 5 : 7);
+        if ((size_t)a.n * C * W25 * 4 > kFovealStreamBytes) {
+            if (a.p.variant == LMAZE_VARIANT_V1) a.p.launch_hint = 0x220;
+            else if (a.p.variant == LMAZE_VARIANT_V2) a.p.launch_hint = 0x35;
+            else if (a.p.variant == LMAZE_VARIANT_V4) a.p.launch_hint = 0x120;
+        }
+    }
     if (MODE == FM_STEP) {
         hipError_t rc = hipSuccess;
         switch (a.p.variant) {
@@ -1072,7 +1106,7 @@ static int check_foveal(const LmazeFovealParams* p, const uint8_t* layouts, cons
     if (p->n_layouts < 1 || p->n_layouts > LMAZE_MAX_LAYOUTS) return LMAZE_E_LAYOUT;
     if (n < 0 || n > LMAZE_MAX_ENVS) return LMAZE_E_COUNT;
 #ifndef LMAZE_EXPERIMENT
-    if (p->launch_hint & ~0xff) return LMAZE_E_LAYOUT;
+    if (p->launch_hint & ~0x3ff) return LMAZE_E_LAYOUT;
 #endif
     if (v56) {
         if (!b->fgoal_xy || !b->foveal_step_count || !b->foveal_reward || !b->foveal_done || !b->visit || !b->ball1_xy ||

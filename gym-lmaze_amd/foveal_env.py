@@ -272,8 +272,9 @@ class LmazeFovealVecEnv(object):
         torch.cuda.current_stream(self.device).wait_stream(side)
         return RolloutGraph(self, graph, int(actions.shape[0]), needs_epoch)
 
-    # launch policies autotune() tries: LmazeFovealParams.launch_hint = (envs-per-workgroup code << 4) | workgroups per CU
-    CANDIDATES = (0x00, 0x20, 0x26, 0x27, 0x30, 0x34, 0x35, 0x36, 0x43, 0x40)
+    # launch policies autotune() tries: LmazeFovealParams.launch_hint = ((chunks per workgroup - 1) << 8) |
+    # (envs-per-workgroup code << 4) | workgroups per CU
+    CANDIDATES = (0x00, 0x20, 0x26, 0x27, 0x30, 0x34, 0x35, 0x36, 0x43, 0x40, 0x120, 0x126, 0x220, 0x226, 0x130, 0x134)
 
     def autotune(self, actions, goals=None, auto_reset=False, steps=24, candidates=None, warm=100, rounds=3,
                  placement_trials=0):

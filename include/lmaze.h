@@ -246,9 +246,10 @@ typedef struct LmazeFovealParams {
     float reward_move;          /* positiveNominal v1 +0.01 (v1:28); v2/v4 -0.01 (v2:47)               */
     float reward_goal;          /* positiveFull    v1 1.0 (v1:29);   v2/v4 100.0                       */
     int32_t launch_hint;        /* 0 = library default launch policy; else bits 0-3 = workgroups per CU
-                                   (1..8, 0 = no cap), bits 4-7 = log2(envs per workgroup) - 4 + 1, i.e.
-                                   1: 16 envs ... 5: 256 envs (0 = default).  Performance only, never
-                                   results (lmaze_foveal.hip launch_foveal_mode); other bits 0.          */
+                                   (1..8, 0 = no cap), bits 4-7 = envs per workgroup, 2: 32, 3: 64, 4: 128,
+                                   5: 256 (anything else = default), bits 8-9 = chunks of that many envs a
+                                   workgroup takes, minus one.  Performance only, never results
+                                   (lmaze_foveal.hip launch_foveal_mode); other bits 0.                  */
 } LmazeFovealParams;
 
 /* Device pointers, one element per env; entries a variant does not use may be NULL. */

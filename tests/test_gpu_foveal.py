@@ -582,6 +582,7 @@ def test_foveal_launch_hint_never_changes_results(variant):
     """LmazeFovealParams.launch_hint (envs per workgroup, workgroups per CU) is a performance knob only."""
     N, T = 2500, 12
     hints = [0] + [(epb << 4) | cu for epb in (2, 3, 4, 5) for cu in (0, 2, 5)] + [0x13, 0x60]   # incl. unsupported codes
+    hints += [0x120, 0x220, 0x323, 0x130, 0x335, 0x240, 0x100, 0x300]                              # bits 8-9: chunks per workgroup - 1
     envs = []
     for h in hints:
         e = PKG.LmazeFovealVecEnv(N, variant=variant, seed=5)
@@ -601,8 +602,17 @@ def test_foveal_launch_hint_never_changes_results(variant):
         a = torch.from_numpy(rs.randint(0, hi, N).astype(np.int32))
         for e in envs:
             e.step(a)
+    for t in range(T):                       # ... and with the reset fused in (v5: the two-level loop)
+        a = torch.from_numpy(rs.randint(0, hi, N).astype(np.int32))
+        g = torch.from_numpy(rs.randint(0, 25, N).astype(np.int32))
+        for e in envs:
+            if variant == "v5":
+                e.hier_step(a, g)
+            else:
+                e.step(a, auto_reset=True)
     ref = envs[0]
     h0 = ref.host_state()
+    assert ref._epoch > 0
     for e in envs[1:]:
         h = e.host_state()
         for k in h0:
@@ -616,7 +626,7 @@ def test_foveal_launch_hint_never_changes_results(variant):
 
 def test_foveal_bad_launch_hint_is_refused():
     e = PKG.LmazeFovealVecEnv(8, variant="v2", seed=1)
-    e.params.launch_hint = 0x100
+    e.params.launch_hint = 0x400
     with pytest.raises(PKG._abi.LmazeError):
         e.step(torch.zeros(8, dtype=torch.int32))
 

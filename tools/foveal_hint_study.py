@@ -15,6 +15,10 @@ pkg = importlib.import_module("gym-lmaze_amd")
 N, K = 1 << 20, 60
 variants = sys.argv[1:] or ["v1", "v2", "v4", "v5"]
 hints = [0] + [(e << 4) | c for e in (2, 3, 4, 5) for c in (0, 2, 3, 4, 6)]
+if os.environ.get('HINTS'):
+    hints = [int(x, 16) for x in os.environ['HINTS'].split(',')]
+else:
+    hints += [(m << 8) | (e << 4) | c for m in (1, 2, 3) for e in (2, 3) for c in (0, 4, 6)]      # bits 8-9: chunks per workgroup - 1
 for variant in variants:
     env = pkg.LmazeFovealVecEnv(N, variant=variant, seed=1)
     hi = 4 if variant in ("v1", "v5") else 25
@@ -51,7 +55,7 @@ for variant in variants:
             e1.synchronize()
             ms = e0.elapsed_time(e1) / K
             best[h] = min(ms, best.get(h, ms))
-    print(json.dumps({"variant": variant, "envs": N, "ms_by_hint": {"0x%02x" % h: round(v, 4) for h, v in best.items()},
-                      "best": "0x%02x" % min(best, key=best.get)}), flush=True)
+    print(json.dumps({"variant": variant, "envs": N, "ms_by_hint": {"0x%03x" % h: round(v, 4) for h, v in best.items()},
+                      "best": "0x%03x" % min(best, key=best.get)}), flush=True)
     del env, acts, goals
     torch.cuda.empty_cache()
