@@ -232,6 +232,55 @@ __device__ __forceinline__ void place_from_list(const uint16_t* list, int count,
     }
 }
 
+__device__ __forceinline__ int kth_set_bit(unsigned long long m, int k) {   // position of the k-th (0-based) set bit
+    int pos = 0;
+#pragma unroll
+    for (int sh = 32; sh > 0; sh >>= 1) {
+        const unsigned long long low = m & ((1ull << sh) - 1ull);
+        const int c = __popcll(low);
+        if (k >= c) { k -= c; m >>= sh; pos += sh; } else { m = low; }
+    }
+    return pos;
+}
+
+// placement from the accepted cells as bit masks (bit c of the NS x 64-bit string = cell c accepted): same rule and
+// same ranking (row-major) as place_from_list
+template <int NS>
+__device__ __forceinline__ int kth_cell_of_masks(const unsigned long long (&m)[NS], int k) {
+    unsigned long long sel = m[0];
+    int base = 0;
+    bool found = false;
+#pragma unroll
+    for (int j = 0; j < NS; ++j) {
+        const int c = __popcll(m[j]);
+        if (!found) {
+            if (k < c) { sel = m[j]; base = j * 64; found = true; }
+            else k -= c;
+        }
+    }
+    return found ? base + kth_set_bit(sel, k) : -1;
+}
+
+template <int VARIANT, int NS>
+__device__ __forceinline__ void place_from_masks(const unsigned long long (&m)[NS], int count, uint4 r, int& ball_cell, int& goal_cell) {
+    ball_cell = -1;
+    goal_cell = -1;
+    if (VARIANT == LMAZE_VARIANT_V3) {
+        int kg = -1;
+        if (count > 0) {
+            kg = (int)__umulhi(r.x, (uint32_t)count);
+            goal_cell = kth_cell_of_masks<NS>(m, kg);
+        }
+        if (count > 1) {
+            int kb = (int)__umulhi(r.y, (uint32_t)(count - 1));
+            kb += (kb >= kg);
+            ball_cell = kth_cell_of_masks<NS>(m, kb);
+        }
+    } else if (count > 0) {
+        ball_cell = kth_cell_of_masks<NS>(m, (int)__umulhi(r.y, (uint32_t)count));
+    }
+}
+
 // k-th accepted cell (row-major, 0-based) of one layout, found by a whole wave with ballots;
 // every lane returns the same cell (-1 if there are fewer than k+1)
 template <int VARIANT>

@@ -63,16 +63,19 @@ __device__ __forceinline__ EnvIn load_env(const StepArgs& a, int64_t e) {
         // branch-free (a load under a branch is waited for where the branch ends, in front of whatever else is in flight):
         // without the fused reset the lane reads byte 0 of the layout instead -- one cached address, no traffic
         const uint8_t* dp = a.auto_reset ? a.done + e : a.layout;
-        const int dv = *dp;
-        in.was_done = a.auto_reset ? dv : 0;
+        // ... and the byte is kept as loaded: every use is `a.auto_reset && in.was_done`.  A select here is a USE of the
+        // loaded value inside the caller's `if (tid < nb)`: the wave then waits for its state loads before the set-up's
+        // layout loads are even issued -- two global round trips in series at the head of every workgroup.
+        in.was_done = *dp;
     }
     return in;
 }
 
 // one env of phase 1 (layout in LDS); returns the env's ball (and goal) cell index for phase 2
-template <int VARIANT, bool DO_STEP>
+// `place(draw, ball_cell, goal_cell)` = the fused reset's placement over the accepted cells (a list in LDS or bit masks)
+template <int VARIANT, bool DO_STEP, class Place>
 __device__ __forceinline__ void env_phase1(const StepArgs& a, const uint8_t* lay, int G, int64_t e, EnvIn in,
-                                           const uint16_t* spawn, int spawn_count, int& ball_cell, int& goal_cell) {
+                                           Place place, int& ball_cell, int& goal_cell) {
     constexpr bool V3 = VARIANT == LMAZE_VARIANT_V3;
     int2 b = in.b, g = in.g;
     if (DO_STEP) {
@@ -80,7 +83,7 @@ __device__ __forceinline__ void env_phase1(const StepArgs& a, const uint8_t* lay
         float r_in = in.r;
         if (a.auto_reset && in.was_done) {  // reference reset(): placement + zeroed counters
             int bc, gc;
-            place_from_list<VARIANT>(spawn, spawn_count, env_draw(a.seed, launch_epoch(a.epoch, a.epoch_in), a.env_base + e), bc, gc);
+            place(env_draw(a.seed, launch_epoch(a.epoch, a.epoch_in), a.env_base + e), bc, gc);
             if (bc >= 0) b = make_int2(bc / G, bc % G);
             if (V3 && gc >= 0) {
                 g = make_int2(gc / G, gc % G);
@@ -150,6 +153,14 @@ __global__ __launch_bounds__(LMAZE_BLOCK) void step_shared_kernel(const StepArgs
 
     EnvIn in{};
     if (tid < nb) in = load_env<VARIANT, DO_STEP>(a, blockbase + tid);
+    // Streaming regime without the fused reset: the state loads are waited for BEFORE the set-up's layout loads go out.
+    // That is a second round trip in series at the head of every workgroup, and it is faster: 1M x 11x11 at the default
+    // policy 76.1-78.2 us on three boxes with it, 85-93 without (then only a narrow (5, 1) / (4, 2) reaches 77) --
+    // the pause staggers the workgroups of a CU, fewer of them stream their ranges at the same moment (the regime
+    // DESIGN 5.3 describes).  With the fused reset the set-up is longer and staggers by itself: 78.5-83 us without
+    // the wait against 84-86 with it.  (Found when the done flag's `auto_reset ? byte : 0` select -- a use of a loaded
+    // value inside the branch above -- turned out to have been that wait all along.)
+    if (DO_STEP && NT && !autoreset) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 
     // Large batches (NT): the first 256 workgroups touch every 64-byte line of this step's action row at kernel
     // start -- ONE burst of reads before the write stream saturates -- so that the chunk loads later in the
@@ -169,6 +180,9 @@ __global__ __launch_bounds__(LMAZE_BLOCK) void step_shared_kernel(const StepArgs
         if (autoreset) warmed += warm_lines(a.done, a.n, 256);
     }
 
+    constexpr int NSM = GT ? (GT * GT + 63) / 64 : 1;
+    unsigned long long okm[NSM] = {};                             // GT != 0: accepted spawn cells, 64 per word
+    int okcount = 0;
     if (GT != 0) {
         // Set-up with ONE global round trip: every layout byte this lane needs -- its cells for the LDS copy and the
         // pattern, and (wave 0, fused reset) the cells it ranks for the spawn list -- is loaded into registers before
@@ -181,7 +195,6 @@ __global__ __launch_bounds__(LMAZE_BLOCK) void step_shared_kernel(const StepArgs
         for (int j = 0; j < NL; ++j) {
             cb[j] = a.layout[min(tid + j * LMAZE_BLOCK, CG - 1)];     // unconditional (clamped): a load under a branch is
         }                                                             // waited for where the branch ends
-        const bool ranks = autoreset && tid < 64;
         if (autoreset) {                                              // uniform
 #pragma unroll
             for (int j = 0; j < NS; ++j) sb[j] = a.layout[min((tid & 63) + j * 64, CG - 1)];
@@ -195,17 +208,17 @@ __global__ __launch_bounds__(LMAZE_BLOCK) void step_shared_kernel(const StepArgs
                 for (int g = 0; g < GRP; ++g) pat[g * CG + c] = bits;
             }
         }
-        if (ranks) {   // wave 0: the accepted spawn cells in row-major order (lmaze_common.h wave_build_spawn_list)
-            int count = 0;
+        if (autoreset) {
+            // the accepted spawn cells as NS ballots, bit c of the string = cell c accepted: every wave ranks the same
+            // bytes, so the masks are wave-uniform scalars and nothing goes through LDS.  (Round 2: as a compacted
+            // list built by wave 0 in front of the barrier the fused reset cost 4.7 of 83 us at 1M x 11x11 even
+            // when no env was done -- the list is only read by the few lanes that reset.)
 #pragma unroll
             for (int j = 0; j < NS; ++j) {
-                const int c = tid + j * 64;
-                const bool ok = c < CG && interior(c, G) && spawn_ok<VARIANT>(sb[j]);
-                const unsigned long long m = __ballot(ok);
-                if (ok) spawn[count + __popcll(m & ((1ull << tid) - 1ull))] = (uint16_t)c;
-                count += __popcll(m);
+                const int c = (tid & 63) + j * 64;
+                okm[j] = __ballot(c < CG && interior(c, G) && spawn_ok<VARIANT>(sb[j]));
+                okcount += __popcll(okm[j]);
             }
-            if (tid == 0) spawn_count_s = count;
         }
     } else {
         for (int i = tid; i < CELLS; i += LMAZE_BLOCK) lay[i] = a.layout[i];
@@ -233,7 +246,12 @@ __global__ __launch_bounds__(LMAZE_BLOCK) void step_shared_kernel(const StepArgs
         if (le < nb) {
             const int64_t e = blockbase + le;
             int bc, gc;
-            env_phase1<VARIANT, DO_STEP>(a, lay, G, e, in, spawn, autoreset ? spawn_count_s : 0, bc, gc);
+            if (GT != 0) {
+                env_phase1<VARIANT, DO_STEP>(a, lay, G, e, in, [&](uint4 d, int& pb, int& pg) { place_from_masks<VARIANT, NSM>(okm, okcount, d, pb, pg); }, bc, gc);
+            } else {
+                const int cnt = autoreset ? spawn_count_s : 0;
+                env_phase1<VARIANT, DO_STEP>(a, lay, G, e, in, [&](uint4 d, int& pb, int& pg) { place_from_list<VARIANT>(spawn, cnt, d, pb, pg); }, bc, gc);
+            }
             const int off = (GT != 0) ? (le % GRP) * CELLS : 0;
             bf = off + bc;
             if (V3 && gc >= 0) gf = off + gc;
@@ -577,16 +595,6 @@ __global__ __launch_bounds__(LMAZE_BLOCK) void step_perenv_wave_kernel(const Ste
 // 16 KiB, 16 stores per lane, store k of lane l covering cells 4(l % 16)..+3 of env l/16 + 4k -- the pattern
 // int4 is loop-invariant per lane.  Fused auto-reset: the accepted spawn cells are a 64-bit ballot.
 // ------------------------------------------------------------------------------------
-__device__ __forceinline__ int kth_set_bit(unsigned long long m, int k) {   // position of the k-th (0-based) set bit
-    int pos = 0;
-#pragma unroll
-    for (int sh = 32; sh > 0; sh >>= 1) {
-        const unsigned long long low = m & ((1ull << sh) - 1ull);
-        const int c = __popcll(low);
-        if (k >= c) { k -= c; m >>= sh; pos += sh; } else { m = low; }
-    }
-    return pos;
-}
 
 // EPW = envs per wave (64, 32 or 16: fewer envs per wave = more, shorter waves to hide the load latency with)
 // Tried and dropped (round 2): storing the ball-free planes first -- they need the 64-byte layout only -- and
@@ -847,10 +855,11 @@ static hipError_t launch_one(const StepArgs& a, int layout_mode, hipStream_t s) 
         // launch_hint bits 10-11: envs per workgroup, 1: 64, 2: 32 (0 = default).  Round 2, once the set-up was one global
         // round trip: v0 11x11 1M, 32 envs (15 KiB of planes) per workgroup, uncapped, one chunk 76.1-76.6 us on every
         // placement of the observation buffer tried, against 78.6-80.9 for 64 envs at (3, 2) / (3, 1) (16 envs: 90+);
-        // with the fused reset 64 envs at (3, 2) 85-86, 32 envs 84-86; (4, 1) at 64 envs 79 on one box, 95 on the next.
+        // with the fused reset (after its set-up lost the compacted spawn list and the early wait) 32 envs uncapped 78.8-83.5
+        // on two boxes, 64 envs at (3, 2) 81 / 95-97, at (3, 1) 81-84.
         int sel = (a.launch_hint >> 10) & 3;
         const bool streaming = a.obs != nullptr && (size_t)a.n * GT * GT * 4 > kNonTemporalObsBytes;
-        if (sel == 0) sel = (GT == 11 && VARIANT == LMAZE_VARIANT_V0 && DO_STEP && !a.auto_reset && streaming) ? 2 : 1;
+        if (sel == 0) sel = (GT == 11 && VARIANT == LMAZE_VARIANT_V0 && DO_STEP && streaming) ? 2 : 1;
         if (sel == 2) return launch_shared<GT, VARIANT, DO_STEP, 32>(a, s);
         return launch_shared<GT, VARIANT, DO_STEP, 64>(a, s);
     } else if constexpr (GT == 14 || GT == 18) {
