@@ -24,6 +24,7 @@ __device__ __forceinline__ void st16(float* p, size_t q, v4f v) {
 
 // MODE 0: the workgroup stripes its chunk, 4 KiB per iteration (the step kernels' schedule)
 // MODE 1: each wave owns a contiguous quarter of the chunk, 1 KiB per iteration
+// MODE 5: wave-autonomous pieces (see the kernel)
 // MODE 3: MODE 0, but workgroup b starts at iteration (b * grp) mod iterations of its chunk and wraps
 // MODE 2: chunk interleaved over a group of `grp` workgroups: workgroup w of the group writes the 4-KiB pieces
 //         w, w + grp, w + 2 grp ... of the group's grp*chunk bytes (the group's front stays compact)
@@ -33,13 +34,22 @@ __global__ __launch_bounds__(256) void chunk_kernel(float* dst, int chunk16, siz
     extern __shared__ int4 pad[];
     const int tid = threadIdx.x;
     float seed = 1.0f;
-    if (dep) seed = (float)dep[(size_t)blockIdx.x * 64 + (tid & 63)];      // a dependent load in front of the stores
+    if (dep) seed = (float)dep[(size_t)(blockIdx.x & 0x3ffff) * 64 + (tid & 63)];      // a dependent load in front of the stores
     const v4f v = {seed, 0.f, 1.f, 0.f};
     if (MODE == 0) {
         const size_t base = (size_t)blockIdx.x * chunk16;
         for (int q = tid; q < chunk16 && base + q < n16; q += 256) {
             st16<NT>(dst, base + q, v);
             if (pace) __builtin_amdgcn_s_sleep(1);
+        }
+    } else if (MODE == 5) {
+        // wave-autonomous pieces: global wave w writes pieces w, w + W, w + 2W ... (W = waves of the grid) of `chunk16`
+        // 16-byte stores each (a piece = 8 envs of 11x11 = 242 stores, ...), `grp` pieces per wave, a dependent load first
+        const int wpb = blockDim.x >> 6, lane = tid & 63;
+        const size_t W = (size_t)gridDim.x * wpb, w0 = (size_t)blockIdx.x * wpb + (tid >> 6);
+        for (int k = 0; k < grp; ++k) {
+            const size_t base = (w0 + (size_t)k * W) * chunk16;
+            for (int q = lane; q < chunk16 && base + q < n16; q += 64) st16<NT>(dst, base + q, v);
         }
     } else if (MODE == 3) {                                                  // MODE 0 with the start rotated per workgroup (grp = multiplier)
         const size_t base = (size_t)blockIdx.x * chunk16;
@@ -82,6 +92,7 @@ static size_t lds_for_per_cu(int k) {
 
 int main(int argc, char** argv) {
     const int rounds = argc > 1 ? atoi(argv[1]) : 7, iters = argc > 2 ? atoi(argv[2]) : 20;
+    const bool only_wave = argc > 3 && std::string(argv[3]) == "wave";       // wave-autonomous pieces only
     const bool only_rot = argc > 3 && std::string(argv[3]) == "rotate";      // the chunk-size x rotation study only
     const size_t bytes = (size_t)(1 << 20) * 500, n16 = bytes / 16;
     float* d;
@@ -104,6 +115,12 @@ int main(int argc, char** argv) {
                              else hipLaunchKernelGGL((chunk_kernel<false, 0>), dim3(blocks), dim3(256), lds, st, d, chunk16, n16, grp, pace, dp); }
             else if (mode == 1) { if (nt) hipLaunchKernelGGL((chunk_kernel<true, 1>), dim3(blocks), dim3(256), lds, st, d, chunk16, n16, grp, pace, dp);
                                   else hipLaunchKernelGGL((chunk_kernel<false, 1>), dim3(blocks), dim3(256), lds, st, d, chunk16, n16, grp, pace, dp); }
+            else if (mode == 5) {
+                const int wpb = pace > 0 ? pace : 4;                      // `pace` carries the waves per workgroup
+                const size_t pieces = (n16 + chunk16 - 1) / chunk16, waves = (pieces + grp - 1) / grp;
+                const unsigned blk = (unsigned)((waves + wpb - 1) / wpb);
+                if (nt) hipLaunchKernelGGL((chunk_kernel<true, 5>), dim3(blk), dim3(64 * wpb), lds, st, d, chunk16, n16, grp, 0, dp);
+                else hipLaunchKernelGGL((chunk_kernel<false, 5>), dim3(blk), dim3(64 * wpb), lds, st, d, chunk16, n16, grp, 0, dp); }
             else if (mode == 3) { if (nt) hipLaunchKernelGGL((chunk_kernel<true, 3>), dim3(blocks), dim3(256), lds, st, d, chunk16, n16, grp, pace, dp);
                                   else hipLaunchKernelGGL((chunk_kernel<false, 3>), dim3(blocks), dim3(256), lds, st, d, chunk16, n16, grp, pace, dp); }
             else { if (nt) hipLaunchKernelGGL((chunk_kernel<true, 2>), dim3(blocks), dim3(256), lds, st, d, chunk16, n16, grp, pace, dp);
@@ -112,9 +129,19 @@ int main(int argc, char** argv) {
     };
     for (int nt = 0; nt < 2; ++nt) {
         add("stripe", 0, nt, 4096, 0, 1, 0, false);                 // one store per thread: the fill
-        if (!only_rot)
+        if (!only_rot && !only_wave)
         for (int cb : {8192, 16384, 32768, 65536})
             for (int cu : {0, 3, 5}) add("stripe", 0, nt, cb, cu, 1, 0, false);
+        if (only_wave) {
+            for (int pb : {1024, 1936, 3872, 4096, 7744})
+                for (int wpb : {1, 4})
+                    for (int m : {1, 2, 4})
+                        for (int cu : {0, 3, 5}) {
+                            if (wpb == 1 && cu) continue;
+                            add("wave-piece", 5, nt, pb, cu, m, wpb, true);
+                        }
+            continue;
+        }
         if (only_rot) {
             for (int cb : {15488, 16384, 18432, 30976, 32768, 36864, 16000, 32000, 12800, 25600}) {
                 add("stripe", 0, nt, cb, 0, 1, 0, false);
