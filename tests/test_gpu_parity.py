@@ -346,8 +346,13 @@ def test_reset_placement_is_uniform_over_accepted_cells():
 # 4b. fused auto-reset == reset(mask=done) then step, bit for bit (incl. the Philox epochs)
 # ----------------------------------------------------------------------------------------
 @pytest.mark.parametrize("variant", ["v0", "v3"])
-@pytest.mark.parametrize("shared,G", [(True, 8), (True, 11), (True, 12), (True, 9), (False, 8), (False, 11), (False, 32), (False, 16)])
-def test_fused_autoreset_equals_reset_then_step(variant, shared, G):
+@pytest.mark.parametrize("shared,G,hint", [(True, 8, 0), (True, 11, 0), (True, 12, 0), (True, 9, 0), (False, 8, 0), (False, 11, 0),
+                                           (False, 32, 0), (False, 16, 0),
+                                           # every compile-time size of the shared kernel (spawn cells as 1 / 2 / 4 / 6 / 16 ballots),
+                                           # the 8x8 workgroup kernel (bit 8), 11x11 at 32 and 64 envs per workgroup, several chunks
+                                           (True, 14, 0), (True, 18, 0), (True, 32, 0), (True, 8, 0x100), (True, 8, 0x123),
+                                           (True, 11, 0x818), (True, 11, 0x423), (True, 11, 0x832), (True, 12, 0x832)])
+def test_fused_autoreset_equals_reset_then_step(variant, shared, G, hint):
     N, T, seed = 2500, 60, 21
     kw = dict(variant=variant, seed=seed, step_limit=7, env_base=1000)   # short episodes: many resets
     if shared:
@@ -356,6 +361,7 @@ def test_fused_autoreset_equals_reset_then_step(variant, shared, G):
     else:
         lay = bordered_random_layouts(N, G, 300 + G)
         fused, split = PKG.LmazeVecEnv(N, per_env_layouts=lay, **kw), PKG.LmazeVecEnv(N, per_env_layouts=lay, **kw)
+    fused.params.launch_hint = hint
     rs = np.random.RandomState(G)
     n_resets = 0
     for t in range(T):
@@ -552,7 +558,7 @@ def test_fused_autoreset_fuzz():
         variant = "v3" if rs.rand() < 0.5 else "v0"
         shared = bool(rs.rand() < 0.5)
         G = int(rs.randint(5, 41))
-        test_fused_autoreset_equals_reset_then_step(variant, shared, G)
+        test_fused_autoreset_equals_reset_then_step(variant, shared, G, 0)
 
 
 # ----------------------------------------------------------------------------------------
