@@ -206,6 +206,8 @@ __global__ __launch_bounds__(LMAZE_BLOCK) void foveal_kernel(const FovealArgs a)
     int nb = (int)min((int64_t)EPB, a.n - blockbase);
     if (tid == 0) any_skip = 0;
     for (int i = tid; i < EPB * 12; i += LMAZE_BLOCK) obits[i] = 0u;       // obits and lbits
+    // the reset epoch, read in front of every store (one uniform scalar load; lmaze_step.hip step_shared_kernel)
+    const uint64_t epoch = launch_epoch(a.epoch, a.epoch_in);
     if (MODE == FM_STEP && AR) pass_epoch_on(a.epoch_in, a.epoch_out);
     // large batches: the first 256 workgroups touch every 64-byte line of this step's action array at kernel
     // start, one burst of reads, so that the per-workgroup loads later in the launch hit the memory-side cache
@@ -394,7 +396,7 @@ __global__ __launch_bounds__(LMAZE_BLOCK) void foveal_kernel(const FovealArgs a)
                     const bool plan = ld || gd;
                     bool planned = false;
                     if (gd) {                                          // reset(): v5:104-150, as FM_RESET below
-                        const uint4 d = env_draw(a.seed, launch_epoch(a.epoch, a.epoch_in), a.env_base + e);
+                        const uint4 d = env_draw(a.seed, epoch, a.env_base + e);
                         lid = (int)__umulhi(d.z, (uint32_t)L);         // v5:105 setGrid first
                         int goal_cell, ball_cell;
                         place_goal_ball(rowgoal + lid * G, rowball + lid * G, G, d, goal_cell, ball_cell);
@@ -520,7 +522,7 @@ __global__ __launch_bounds__(LMAZE_BLOCK) void foveal_kernel(const FovealArgs a)
             const bool fused = MODE == FM_STEP && AR && a.b.done[e] != 0;
             if ((MODE == FM_RESET && !r.skip) || fused) {              // reset(): v2:80-123, v4:95-163
                 if (a.place || fused) {
-                    const uint4 d = env_draw(a.seed, launch_epoch(a.epoch, a.epoch_in), a.env_base + e);
+                    const uint4 d = env_draw(a.seed, epoch, a.env_base + e);
                     const int lid_new = (int)__umulhi(d.z, (uint32_t)L);
                     if (V4) lid = lid_new;                             // v4:97 setGrid first
                     lid = clampi(lid, 0, L - 1);
