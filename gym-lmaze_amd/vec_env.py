@@ -286,7 +286,7 @@ class LmazeVecEnv(object):
     DEFAULT_POLICY = (0, 0)       # launch_hint = 0: the library's per-shape default (lmaze_step.hip launch_shared)
     # a third element selects the envs per workgroup where the kernel offers a choice (11x11, 12x12: 1 = 64, 2 = 32)
     CANDIDATES = ((0, 0), (2, 1), (2, 2), (3, 1), (3, 2), (4, 1), (4, 2), (5, 2), (6, 2), (7, 2), (8, 1), (8, 2),
-                  (6, 1, 2), (8, 1, 2), (5, 1, 2), (4, 2, 2), (4, 1, 1), (3, 2, 1))
+                  (6, 1, 2), (8, 1, 2), (5, 1, 2), (4, 2, 2), (3, 1, 2), (4, 1, 1), (3, 2, 1))
 
     @staticmethod
     def launch_hint_of(per_cu, chunks=1, epb_sel=0):
