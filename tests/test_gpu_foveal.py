@@ -599,12 +599,12 @@ def test_foveal_launch_hint_never_changes_results(variant):
         for e in envs:
             e.planner_step(g)
     for t in range(T):
-        a = torch.from_numpy(rs.randint(0, hi, N).astype(np.int32))
+        a = torch.from_numpy(rs.randint(-1, hi + 2, N).astype(np.int32))       # incl. ids the reference raises on (skipped envs)
         for e in envs:
             e.step(a)
     for t in range(T):                       # ... and with the reset fused in (v5: the two-level loop)
-        a = torch.from_numpy(rs.randint(0, hi, N).astype(np.int32))
-        g = torch.from_numpy(rs.randint(0, 25, N).astype(np.int32))
+        a = torch.from_numpy(rs.randint(-1, hi + 2, N).astype(np.int32))
+        g = torch.from_numpy(rs.randint(-1, 27, N).astype(np.int32))
         for e in envs:
             if variant == "v5":
                 e.hier_step(a, g)
