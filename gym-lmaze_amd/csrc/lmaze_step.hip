@@ -764,7 +764,9 @@ static hipError_t launch_shared(const StepArgs& a, hipStream_t s) {
     //   v0 32x32 128K (2,1) 92.3-92.7 / 100-101   fused (3,2) 100-102 (2,1: 142)
     //   v3 11x11 1M   (8,1) 91.3-91.6 / 107       fused (8,1) 97.4-97.7 / 117
     // (On a placement where everything runs fast, v0 11x11 (3,2) and (4,2) reach 76-80 us; LmazeVecEnv.autotune()
-    // finds that out.)  launch_hint bits 0-3 / 4-7 override workgroups per CU / chunks per workgroup.
+    // finds that out.)  Since then v0 11x11 runs 32 envs per workgroup, uncapped, one chunk (launch_one): 76.1-78.9 us,
+    // with the fused reset 78.8-84.6; the 64-env rows above are what launch_hint bits 10-11 = 1 selects.
+    // launch_hint bits 0-3 / 4-7 override workgroups per CU / chunks per workgroup.
     int def_cu = 3, def_m = 2;
     if (GT == 11) {
         if (VARIANT == LMAZE_VARIANT_V3) { def_cu = 8; def_m = 1; }
