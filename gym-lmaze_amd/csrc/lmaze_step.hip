@@ -773,6 +773,8 @@ static hipError_t launch_shared(const StepArgs& a, hipStream_t s) {
         else if (EPB == 32) { def_cu = 8; def_m = 1; }
         else if (a.auto_reset) { def_cu = 3; def_m = 2; }
         else { def_cu = 3; def_m = 1; }
+    } else if (GT == 14 && EPB == 16) {
+        def_cu = 5; def_m = 1;
     } else if (GT == 8 || GT == 12 || GT == 14) {
         def_cu = 2; def_m = 1;
     } else if (GT == 18) {
@@ -881,6 +883,14 @@ static hipError_t launch_one(const StepArgs& a, int layout_mode, hipStream_t s) 
         if (sel == 2) return launch_shared<GT, VARIANT, DO_STEP, 32>(a, s);
         return launch_shared<GT, VARIANT, DO_STEP, 64>(a, s);
     } else if constexpr (GT == 14 || GT == 18) {
+        // launch_hint bits 10-11: envs per workgroup, 1: 32, 2: 16 (0 = default).  1M x 14x14 v0 (861 MB): 16 envs (12 KiB
+        // of planes) at 5 workgroups per CU 120.5 us, at 4 / 6 / uncapped 134 / 142 / 142, against 150-161 for every
+        // policy of 32 envs but (2, 2) (132.5); 512K x 18x18 v3: 16 envs at (4, 1) or (3, 2) 104.3-104.5 against 109.5
+        // for 32 at (2, 1) -- but 118-134 one step to either side, so there it stays a tuner candidate.
+        int sel = (a.launch_hint >> 10) & 3;
+        const bool streaming = a.obs != nullptr && (size_t)a.n * GT * GT * 4 > kNonTemporalObsBytes;
+        if (sel == 0) sel = (GT == 14 && DO_STEP && streaming) ? 2 : 1;
+        if (sel == 2) return launch_shared<GT, VARIANT, DO_STEP, 16>(a, s);
         return launch_shared<GT, VARIANT, DO_STEP, 32>(a, s);
     } else if constexpr (GT == 32) {
         return launch_shared<GT, VARIANT, DO_STEP, 8>(a, s);

@@ -1,0 +1,24 @@
+import importlib, sys, torch, statistics
+sys.path.insert(0, ".")
+lm = importlib.import_module("gym-lmaze_amd")
+def run(env, acts, ar, hint, steps=24):
+    env.params.launch_hint = hint
+    for i in range(6): env.step(acts[i % len(acts)], auto_reset=ar)
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for i in range(steps): env.step(acts[i % len(acts)], auto_reset=ar)
+    e1.record(); torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / steps * 1e3
+H = lm.LmazeVecEnv.launch_hint_of
+for G, var, N in ((14, "v0", 1 << 20), (14, "v3", 1 << 20), (14, "v0", 1 << 18), (14, "v0", 1 << 22)):
+    acts = torch.randint(0, 4, (max(8, (48 << 20) // N), N), dtype=torch.int32, device="cuda")
+    env = lm.LmazeVecEnv(N, variant=var, layout=lm.layouts.open_room(G))
+    for ar in (False, True):
+        cands = [("default", 0), ("32 2x1", H(2,1,1)), ("32 2x2", H(2,2,1))] + [("16 %dx%d" % (c, m), H(c, m, 2)) for c, m in ((8,1),(6,1),(5,1),(4,1),(5,2),(4,2),(3,2))]
+        res = {k: [] for k, _ in cands}
+        for r in range(3):
+            for name, h in cands:
+                res[name].append(run(env, acts, ar, h))
+        print("G", G, var, N, "AR", ar, {k: round(statistics.median(v), 1) for k, v in res.items()}, flush=True)
+    del env, acts
