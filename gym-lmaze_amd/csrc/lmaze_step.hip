@@ -881,6 +881,7 @@ static hipError_t launch_one(const StepArgs& a, int layout_mode, hipStream_t s) 
         const bool streaming = a.obs != nullptr && (size_t)a.n * GT * GT * 4 > kNonTemporalObsBytes;
         if (sel == 0) sel = (GT == 11 && VARIANT == LMAZE_VARIANT_V0 && DO_STEP && streaming) ? 2 : 1;
         if (sel == 2) return launch_shared<GT, VARIANT, DO_STEP, 32>(a, s);
+        if (sel == 3) return launch_shared<GT, VARIANT, DO_STEP, 16>(a, s);     // EXPERIMENT
         return launch_shared<GT, VARIANT, DO_STEP, 64>(a, s);
     } else if constexpr (GT == 14 || GT == 18) {
         // launch_hint bits 10-11: envs per workgroup, 1: 32, 2: 16 (0 = default).  1M x 14x14 v0 (861 MB): 16 envs (12 KiB

@@ -11,14 +11,18 @@ def run(env, acts, ar, hint, steps=24):
     e1.record(); torch.cuda.synchronize()
     return e0.elapsed_time(e1) / steps * 1e3
 H = lm.LmazeVecEnv.launch_hint_of
-for G, var, N in ((14, "v0", 1 << 20), (14, "v3", 1 << 20), (14, "v0", 1 << 18), (14, "v0", 1 << 22)):
-    acts = torch.randint(0, 4, (max(8, (48 << 20) // N), N), dtype=torch.int32, device="cuda")
+N = 1 << 20
+for G, var in ((12, "v0"), (11, "v3")):
+    acts = torch.randint(0, 4, (48, N), dtype=torch.int32, device="cuda")
     env = lm.LmazeVecEnv(N, variant=var, layout=lm.layouts.open_room(G))
     for ar in (False, True):
-        cands = [("default", 0), ("32 2x1", H(2,1,1)), ("32 2x2", H(2,2,1))] + [("16 %dx%d" % (c, m), H(c, m, 2)) for c, m in ((8,1),(6,1),(5,1),(4,1),(5,2),(4,2),(3,2))]
+        cands = [("default", 0)]
+        for sel, nm in ((1, "64"), (2, "32"), (3, "16")):
+            for c, m in ((8,1),(6,1),(5,1),(4,1),(3,1),(2,1),(5,2),(4,2),(3,2)):
+                cands.append(("%s %dx%d" % (nm, c, m), H(c, m, sel)))
         res = {k: [] for k, _ in cands}
         for r in range(3):
             for name, h in cands:
                 res[name].append(run(env, acts, ar, h))
-        print("G", G, var, N, "AR", ar, {k: round(statistics.median(v), 1) for k, v in res.items()}, flush=True)
+        print("G", G, var, "AR", ar, {k: round(statistics.median(v), 1) for k, v in res.items()}, flush=True)
     del env, acts
