@@ -775,6 +775,8 @@ static hipError_t launch_shared(const StepArgs& a, hipStream_t s) {
         else { def_cu = 3; def_m = 1; }
     } else if (GT == 14 && EPB == 16) {
         def_cu = 5; def_m = 1;
+    } else if (GT == 12 && EPB == 16) {
+        def_cu = 8; def_m = 1;
     } else if (GT == 8 || GT == 12 || GT == 14) {
         def_cu = 2; def_m = 1;
     } else if (GT == 18) {
@@ -879,9 +881,14 @@ static hipError_t launch_one(const StepArgs& a, int layout_mode, hipStream_t s) 
         // on two boxes, 64 envs at (3, 2) 81 / 95-97, at (3, 1) 81-84.
         int sel = (a.launch_hint >> 10) & 3;
         const bool streaming = a.obs != nullptr && (size_t)a.n * GT * GT * 4 > kNonTemporalObsBytes;
-        if (sel == 0) sel = (GT == 11 && VARIANT == LMAZE_VARIANT_V0 && DO_STEP && streaming) ? 2 : 1;
+        // 12x12 (1M envs, 643 MB): 16 envs (9 KiB) per workgroup, uncapped 97.1-97.4 us, (5, 2) 96.0, against 104-105 for 64
+        // envs at (2, 1) and 111-119 for nearly everything else; with the fused reset 103-104 against 109.  (3: 16 envs.)
+        if (sel == 0) {
+            if (GT == 11) sel = (VARIANT == LMAZE_VARIANT_V0 && DO_STEP && streaming) ? 2 : 1;
+            else sel = (DO_STEP && streaming) ? 3 : 1;
+        }
         if (sel == 2) return launch_shared<GT, VARIANT, DO_STEP, 32>(a, s);
-        if (sel == 3) return launch_shared<GT, VARIANT, DO_STEP, 16>(a, s);     // EXPERIMENT
+        if (sel == 3) return launch_shared<GT, VARIANT, DO_STEP, 16>(a, s);
         return launch_shared<GT, VARIANT, DO_STEP, 64>(a, s);
     } else if constexpr (GT == 14 || GT == 18) {
         // launch_hint bits 10-11: envs per workgroup, 1: 32, 2: 16 (0 = default).  1M x 14x14 v0 (861 MB): 16 envs (12 KiB

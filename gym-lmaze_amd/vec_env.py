@@ -284,10 +284,10 @@ class LmazeVecEnv(object):
 
     # launch policies autotune() tries: (workgroups per CU, chunks per workgroup) -> LmazeParams.launch_hint
     DEFAULT_POLICY = (0, 0)       # launch_hint = 0: the library's per-shape default (lmaze_step.hip launch_shared)
-    # a third element selects the envs per workgroup where the kernel offers a choice (11x11, 12x12: 1 = 64, 2 = 32;
+    # a third element selects the envs per workgroup where the kernel offers a choice (11x11, 12x12: 1 = 64, 2 = 32, 3 = 16;
     # 14x14, 18x18: 1 = 32, 2 = 16)
     CANDIDATES = ((0, 0), (2, 1), (2, 2), (3, 1), (3, 2), (4, 1), (4, 2), (5, 2), (6, 2), (7, 2), (8, 1), (8, 2),
-                  (6, 1, 2), (8, 1, 2), (5, 1, 2), (4, 2, 2), (3, 1, 2), (4, 1, 2), (3, 2, 2), (4, 1, 1), (3, 2, 1), (2, 1, 1), (2, 2, 1))
+                  (6, 1, 2), (8, 1, 2), (5, 1, 2), (4, 2, 2), (3, 1, 2), (4, 1, 2), (3, 2, 2), (4, 1, 1), (3, 2, 1), (2, 1, 1), (2, 2, 1), (8, 1, 3), (5, 2, 3))
 
     @staticmethod
     def launch_hint_of(per_cu, chunks=1, epb_sel=0):

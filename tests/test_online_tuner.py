@@ -59,5 +59,5 @@ def test_launch_hint_encoding():
     assert V.launch_hint_of(3, 2) == 0x23 and V.launch_hint_of(8) == 0x18 and V.launch_hint_of(0, 0) == 0
     # (0, 0) = launch_hint 0, the library's per-shape default: always a candidate, and the one kept unless beaten by 1.5 %
     assert V.CANDIDATES[0] == V.DEFAULT_POLICY == (0, 0) and (3, 1) in V.CANDIDATES and (3, 2) in V.CANDIDATES
-    assert all(1 <= c[0] <= 8 and 1 <= c[1] <= 15 and (len(c) == 2 or c[2] in (1, 2)) for c in V.CANDIDATES[1:])
+    assert all(1 <= c[0] <= 8 and 1 <= c[1] <= 15 and (len(c) == 2 or c[2] in (1, 2, 3)) for c in V.CANDIDATES[1:])
     assert V.launch_hint_of(8, 1, 2) == 0x818 and V.launch_hint_of(4, 1, 1) == 0x414
