@@ -135,9 +135,22 @@ __global__ __launch_bounds__(LMAZE_BLOCK) void step_shared_kernel(const StepArgs
     int* maskflag = goalflat + EPB;
     uint8_t* lay = reinterpret_cast<uint8_t*>(maskflag + EPB);
     uint16_t* spawn = reinterpret_cast<uint16_t*>(lay + ((CELLS + 15) & ~15));
+    // v3, compile-time G: where the balls and goals are, as bit strings -- bit f of a group's string = dword f of the
+    // group's GRP*G*G output dwords holds one -- so that a 16-byte store ORs two nibbles into its pattern instead of
+    // comparing eight indices with four positions (v3's render loop was ~100 VALU instructions per store: 1M x 11x11
+    // 94-97 us, 77-79 with the strings; 512K x 18x18 109 -> 103-109).  v0 keeps the comparisons: the strings give the same
+    // best time there (76.7-78.9 us) but only at narrow launch policies -- its extra VALU work paces the stores about right
+    // ("a wait that staggers").  Two buffers, used by alternate chunks.
+    constexpr bool MARKS = GT != 0 && V3;
+    constexpr int GRPT = (GT & 1) ? 4 : 1, NPL = V3 ? 2 : 1;
+    constexpr int WPG = GT ? (GRPT * GT * GT + 31) / 32 : 1;      // words per group string
+    constexpr int NGW = GT ? (EPB / GRPT) * WPG : 1;              // words per plane
+    uint32_t* marks = reinterpret_cast<uint32_t*>(reinterpret_cast<uint8_t*>(spawn) + ((CELLS * 2 + 15) & ~15));   // [2][NPL][NGW]
     __shared__ int spawn_count_s;
 
     const int tid = threadIdx.x;
+    if (MARKS)
+        for (int i = tid; i < 2 * NPL * NGW; i += LMAZE_BLOCK) marks[i] = 0u;
     // A workgroup takes chunks of EPB envs grid-stride (chunk = blockIdx.x, + gridDim.x, ...): with one chunk
     // each (gridDim.x = number of chunks) it is the plain one-chunk kernel; with several, the inputs of the
     // NEXT chunk are loaded while the current one is being stored, so their latency -- several microseconds
@@ -234,9 +247,11 @@ __global__ __launch_bounds__(LMAZE_BLOCK) void step_shared_kernel(const StepArgs
     }
     __syncthreads();
 
+  int buf = 0;
   for (;;) {
     const int64_t next = chunk + gridDim.x;
     const bool has_next = next < nchunks;                         // uniform over the workgroup
+    uint32_t* mk = marks + buf * NPL * NGW;
     EnvIn in_next{};
     int nb_next = 0;
     if (has_next) {                                               // issued now, consumed one chunk later
@@ -260,6 +275,11 @@ __global__ __launch_bounds__(LMAZE_BLOCK) void step_shared_kernel(const StepArgs
             bf = off + bc;
             if (V3 && gc >= 0) gf = off + gc;
             if (masked) mf = a.mask[e] != 0;
+            if (MARKS) {
+                const int gi = (le / GRP) * WPG;
+                atomicOr(&mk[gi + (bf >> 5)], 1u << (bf & 31));
+                if (V3 && gc >= 0) atomicOr(&mk[NGW + gi + (gf >> 5)], 1u << (gf & 31));
+            }
         }
         ballflat[le] = bf;
         if (V3) goalflat[le] = gf;
@@ -276,32 +296,37 @@ __global__ __launch_bounds__(LMAZE_BLOCK) void step_shared_kernel(const StepArgs
     if (GT != 0) {
         const int V4G = PAT >> 2;  // stores per group of GRP envs
         const int4* pat4 = reinterpret_cast<const int4*>(pat);
+        if (MARKS && has_next)                                    // the other buffer, for the next chunk's phase 1
+            for (int i = tid; i < NPL * NGW; i += LMAZE_BLOCK) marks[(buf ^ 1) * NPL * NGW + i] = 0u;
         for (int q = tid; q < nq; q += LMAZE_BLOCK) {
             const int grp = q / V4G;
             const int p = q - grp * V4G;
             int4 v = pat4[p];
             const int p4 = p << 2;
-            if (GRP == 4) {
-                if (masked) {
+            if (masked) {
+                if (GRP == 4) {
                     const int4 m = reinterpret_cast<const int4*>(maskflag)[grp];
                     if (!(m.x | m.y | m.z | m.w)) continue;
+                } else if (!maskflag[grp]) {
+                    continue;
                 }
+            }
+            if (MARKS) {
+                // dwords 4p .. 4p+3 of the group: one nibble of each string (4 divides 32: never across two words)
+                const int w = grp * WPG + (p4 >> 5), sh = p4 & 31;
+                const uint32_t b4 = mk[w] >> sh, g4 = mk[NGW + w] >> sh;
+                v.x |= (int)(b4 & 1u) * LMAZE_OBS_BALL | (int)(g4 & 1u) * LMAZE_OBS_GOAL;
+                v.y |= (int)((b4 >> 1) & 1u) * LMAZE_OBS_BALL | (int)((g4 >> 1) & 1u) * LMAZE_OBS_GOAL;
+                v.z |= (int)((b4 >> 2) & 1u) * LMAZE_OBS_BALL | (int)((g4 >> 2) & 1u) * LMAZE_OBS_GOAL;
+                v.w |= (int)((b4 >> 3) & 1u) * LMAZE_OBS_BALL | (int)((g4 >> 3) & 1u) * LMAZE_OBS_GOAL;
+            } else if (GRP == 4) {
                 const int4 bf = reinterpret_cast<const int4*>(ballflat)[grp];
                 or_at(v, bf.x - p4, LMAZE_OBS_BALL);
                 or_at(v, bf.y - p4, LMAZE_OBS_BALL);
                 or_at(v, bf.z - p4, LMAZE_OBS_BALL);
                 or_at(v, bf.w - p4, LMAZE_OBS_BALL);
-                if (V3) {
-                    const int4 gf = reinterpret_cast<const int4*>(goalflat)[grp];
-                    or_at(v, gf.x - p4, LMAZE_OBS_GOAL);
-                    or_at(v, gf.y - p4, LMAZE_OBS_GOAL);
-                    or_at(v, gf.z - p4, LMAZE_OBS_GOAL);
-                    or_at(v, gf.w - p4, LMAZE_OBS_GOAL);
-                }
             } else {
-                if (masked && !maskflag[grp]) continue;
                 or_at(v, ballflat[grp] - p4, LMAZE_OBS_BALL);
-                if (V3) or_at(v, goalflat[grp] - p4, LMAZE_OBS_GOAL);
             }
             store16<NT>(obs4 + q, v);
         }
@@ -344,6 +369,7 @@ __global__ __launch_bounds__(LMAZE_BLOCK) void step_shared_kernel(const StepArgs
     blockbase = chunk * EPB;
     nb = nb_next;
     in = in_next;
+    buf ^= 1;
   }
   if (warmed == 0x7fedcba9 && a.n < 0) a.done[0] = 1;   // never true: keeps the warming loads alive
 }
@@ -712,11 +738,14 @@ __global__ __launch_bounds__(LMAZE_BLOCK) void step_shared_wave8_kernel(const St
 // smaller buffers keep plain stores so the consumer of the observation finds them on-die.
 static const size_t kNonTemporalObsBytes = (size_t)192 << 20;
 
-static size_t shared_lds_bytes(int G, bool specialised, int epb) {
+static size_t shared_lds_bytes(int G, bool specialised, int epb, bool with_marks) {
     const int cells = G * G;
     const int pat = (specialised && (G & 1)) ? 4 * cells : cells;
-    // pattern + ballflat/goalflat/maskflag + layout bytes + spawn list (uint16 per cell)
-    return (size_t)pat * 4 + 3 * (size_t)epb * 4 + (size_t)((cells + 15) & ~15) + (size_t)((cells * 2 + 15) & ~15);
+    // pattern + ballflat/goalflat/maskflag + layout bytes + spawn list (uint16 per cell) + ball / goal bit strings
+    // (v3: two buffers x two planes x one string per group of envs)
+    const int grp = (specialised && (G & 1)) ? 4 : 1;
+    const size_t marks = (specialised && with_marks) ? (size_t)2 * 2 * (epb / grp) * ((grp * cells + 31) / 32) * 4 : 0;
+    return (size_t)pat * 4 + 3 * (size_t)epb * 4 + (size_t)((cells + 15) & ~15) + (size_t)((cells * 2 + 15) & ~15) + marks;
 }
 
 int perenv_envs_per_block(int G) {
@@ -752,7 +781,7 @@ static size_t lds_for_workgroups_per_cu(int k) {
 template <int GT, int VARIANT, bool DO_STEP, int EPB>
 static hipError_t launch_shared(const StepArgs& a, hipStream_t s) {
     const int64_t blocks = (a.n + EPB - 1) / EPB;
-    size_t lds = shared_lds_bytes(a.grid, GT != 0, EPB);
+    size_t lds = shared_lds_bytes(a.grid, GT != 0, EPB, VARIANT == LMAZE_VARIANT_V3);
     const bool nt = a.obs != nullptr && (size_t)a.n * a.grid * a.grid * 4 > kNonTemporalObsBytes;
     // Defaults of the streaming regime, per shape, re-measured in round 2 after the set-up went to one global round trip
     // (tools/policy_by_shape.py, three separately allocated batches per shape, all on a placement where only one or two
@@ -769,16 +798,18 @@ static hipError_t launch_shared(const StepArgs& a, hipStream_t s) {
     // launch_hint bits 0-3 / 4-7 override workgroups per CU / chunks per workgroup.
     int def_cu = 3, def_m = 2;
     if (GT == 11) {
-        if (VARIANT == LMAZE_VARIANT_V3) { def_cu = 8; def_m = 1; }
-        else if (EPB == 32) { def_cu = 8; def_m = 1; }
+        if (EPB == 32) { def_cu = 8; def_m = 1; }
+        else if (VARIANT == LMAZE_VARIANT_V3) { def_cu = 8; def_m = 1; }
         else if (a.auto_reset) { def_cu = 3; def_m = 2; }
         else { def_cu = 3; def_m = 1; }
     } else if (GT == 14 && EPB == 16) {
-        def_cu = 5; def_m = 1;
+        def_cu = 5; def_m = VARIANT == LMAZE_VARIANT_V3 ? 2 : 1;     // v3 (bit-string render): (5, 2) 127 us, (5, 1) 150
     } else if (GT == 12 && EPB == 16) {
         def_cu = 8; def_m = 1;
     } else if (GT == 8 || GT == 12 || GT == 14) {
         def_cu = 2; def_m = 1;
+    } else if (GT == 18 && EPB == 16) {
+        def_cu = 5; def_m = 1;
     } else if (GT == 18) {
         def_cu = 2; def_m = a.auto_reset ? 2 : 1;
     } else if (GT == 32) {
@@ -884,7 +915,7 @@ static hipError_t launch_one(const StepArgs& a, int layout_mode, hipStream_t s) 
         // 12x12 (1M envs, 643 MB): 16 envs (9 KiB) per workgroup, uncapped 97.1-97.4 us, (5, 2) 96.0, against 104-105 for 64
         // envs at (2, 1) and 111-119 for nearly everything else; with the fused reset 103-104 against 109.  (3: 16 envs.)
         if (sel == 0) {
-            if (GT == 11) sel = (VARIANT == LMAZE_VARIANT_V0 && DO_STEP && streaming) ? 2 : 1;
+            if (GT == 11) sel = (DO_STEP && streaming) ? 2 : 1;
             else sel = (DO_STEP && streaming) ? 3 : 1;
         }
         if (sel == 2) return launch_shared<GT, VARIANT, DO_STEP, 32>(a, s);
@@ -897,7 +928,7 @@ static hipError_t launch_one(const StepArgs& a, int layout_mode, hipStream_t s) 
         // for 32 at (2, 1) -- but 118-134 one step to either side, so there it stays a tuner candidate.
         int sel = (a.launch_hint >> 10) & 3;
         const bool streaming = a.obs != nullptr && (size_t)a.n * GT * GT * 4 > kNonTemporalObsBytes;
-        if (sel == 0) sel = (GT == 14 && DO_STEP && streaming) ? 2 : 1;
+        if (sel == 0) sel = ((GT == 14 || VARIANT == LMAZE_VARIANT_V3) && DO_STEP && streaming) ? 2 : 1;   // v3 18x18 since its render went to bit strings: 16 envs at 4-5 per CU 109 us (with the fused reset 5-8 per CU 103-107) against 112-120
         if (sel == 2) return launch_shared<GT, VARIANT, DO_STEP, 16>(a, s);
         return launch_shared<GT, VARIANT, DO_STEP, 32>(a, s);
     } else if constexpr (GT == 32) {
