@@ -802,6 +802,10 @@ static hipError_t launch_shared(const StepArgs& a, hipStream_t s) {
         else if (VARIANT == LMAZE_VARIANT_V3) { def_cu = 8; def_m = 1; }
         else if (a.auto_reset) { def_cu = 3; def_m = 2; }
         else { def_cu = 3; def_m = 1; }
+    } else if (GT == 32 && EPB == 4) {
+        def_cu = 5; def_m = 1;
+    } else if (GT == 8 && EPB == 64) {
+        def_cu = 4; def_m = 1;
     } else if (GT == 14 && EPB == 16) {
         def_cu = 5; def_m = VARIANT == LMAZE_VARIANT_V3 ? 2 : 1;     // v3 (bit-string render): (5, 2) 127 us, (5, 1) 150
     } else if (GT == 12 && EPB == 16) {
@@ -903,6 +907,11 @@ static hipError_t launch_one(const StepArgs& a, int layout_mode, hipStream_t s) 
             else hipLaunchKernelGGL((step_shared_wave8_kernel<VARIANT, DO_STEP, 16>), grid, block, 0, s, a);
             return hipGetLastError();
         }
+        // large 8x8 batches: launch_hint bits 10-11: 1: 128 envs per workgroup, 2: 64 (16 KiB of planes).  2M envs: 64 envs at
+        // 4 / 5 / 6 / 8 per CU 89.0 / 91.7 / 91.8 / 91.7 us, 128 envs at (2, 1) 92.6, at 3-8 per CU 102-105.
+        int sel = (a.launch_hint >> 10) & 3;
+        if (sel == 0) sel = (DO_STEP && a.obs != nullptr) ? 2 : 1;
+        if (sel == 2) return launch_shared<GT, VARIANT, DO_STEP, 64>(a, s);
         return launch_shared<GT, VARIANT, DO_STEP, 128>(a, s);
     } else if constexpr (GT == 11 || GT == 12) {
         // launch_hint bits 10-11: envs per workgroup, 1: 64, 2: 32 (0 = default).  Round 2, once the set-up was one global
@@ -932,6 +941,13 @@ static hipError_t launch_one(const StepArgs& a, int layout_mode, hipStream_t s) 
         if (sel == 2) return launch_shared<GT, VARIANT, DO_STEP, 16>(a, s);
         return launch_shared<GT, VARIANT, DO_STEP, 32>(a, s);
     } else if constexpr (GT == 32) {
+        // launch_hint bits 10-11: 1: 8 envs per workgroup (32 KiB of planes), 2: 4 envs (16 KiB).  128K / 512K envs, us per
+        // step: 4 envs at (5, 1) 84.0 / 337 and at (4, 1) 85.0 / 323 against 96 / 363 for 8 envs at (2, 1); with the fused
+        // reset 4 envs at (5, 1) 88.6 / 342, at (6, 1) 81.8 / 313, against 102 / 403.
+        int sel = (a.launch_hint >> 10) & 3;
+        const bool streaming = a.obs != nullptr && (size_t)a.n * GT * GT * 4 > kNonTemporalObsBytes;
+        if (sel == 0) sel = (DO_STEP && streaming) ? 2 : 1;
+        if (sel == 2) return launch_shared<GT, VARIANT, DO_STEP, 4>(a, s);
         return launch_shared<GT, VARIANT, DO_STEP, 8>(a, s);
     } else {  // unspecialised G: three sizes cover [3, 64]
         if (a.grid >= 23) return launch_shared<GT, VARIANT, DO_STEP, 16>(a, s);
