@@ -23,6 +23,11 @@
 
 namespace lmaze {
 
+// Obs buffers larger than this are written with non-temporal stores: they cannot stay in the
+// 256 MiB Infinity Cache anyway, and streaming them past L2 measured 0-7 % faster on MI355X;
+// smaller buffers keep plain stores so the consumer of the observation finds them on-die.
+static constexpr size_t kNonTemporalObsBytes = (size_t)192 << 20;
+
 template <bool NT>
 __device__ __forceinline__ void store16(int4* p, const int4& v) {
     typedef int v4i __attribute__((ext_vector_type(4)));
@@ -478,6 +483,8 @@ __global__ __launch_bounds__(LMAZE_BLOCK) void step_perenv_kernel(const StepArgs
         if (V3) goalcell[tid] = gcell;
     }
     if (a.obs == nullptr) return;
+    // large batches: non-temporal stores, as in the other kernels (1M x 11x11 per-env layouts, 8-KiB tiles: 121 -> 102 us)
+    const bool stream = (size_t)a.n * CELLS * 4 > kNonTemporalObsBytes;   // uniform
     __syncthreads();
 
     int32_t* obs = a.obs + (size_t)blockbase * CELLS;
@@ -513,7 +520,8 @@ __global__ __launch_bounds__(LMAZE_BLOCK) void step_perenv_kernel(const StepArgs
                 if (++c == CELLS) { c = 0; ++le; }
             }
         }
-        obs4[q] = make_int4(vals[0], vals[1], vals[2], vals[3]);
+        if (stream) store16<true>(obs4 + q, make_int4(vals[0], vals[1], vals[2], vals[3]));
+        else obs4[q] = make_int4(vals[0], vals[1], vals[2], vals[3]);
     }
     const int f = (nq << 2) + tid;
     if (f < R) {
@@ -733,10 +741,6 @@ __global__ __launch_bounds__(LMAZE_BLOCK) void step_shared_wave8_kernel(const St
 // ------------------------------------------------------------------------------------
 // host launchers
 // ------------------------------------------------------------------------------------
-// Obs buffers larger than this are written with non-temporal stores: they cannot stay in the
-// 256 MiB Infinity Cache anyway, and streaming them past L2 measured 0-7 % faster on MI355X;
-// smaller buffers keep plain stores so the consumer of the observation finds them on-die.
-static const size_t kNonTemporalObsBytes = (size_t)192 << 20;
 
 static size_t shared_lds_bytes(int G, bool specialised, int epb, bool with_marks) {
     const int cells = G * G;
@@ -748,9 +752,9 @@ static size_t shared_lds_bytes(int G, bool specialised, int epb, bool with_marks
     return (size_t)pat * 4 + 3 * (size_t)epb * 4 + (size_t)((cells + 15) & ~15) + (size_t)((cells * 2 + 15) & ~15) + marks;
 }
 
-int perenv_envs_per_block(int G) {
+int perenv_envs_per_block(int G, int layout_bytes) {
     const int cells = G * G;
-    int epb = (16384 / cells) & ~15;  // about 16 KiB of layouts per workgroup
+    int epb = (layout_bytes / cells) & ~15;
     if (epb < 16) epb = 16;
     if (epb > LMAZE_BLOCK) epb = LMAZE_BLOCK;
     return epb;
@@ -870,7 +874,9 @@ static hipError_t launch_perenv(const StepArgs& a, hipStream_t s) {
         if (a.grid == 64) return launch_perenv_wave<64, VARIANT, DO_STEP>(a, s);
     }
     StepArgs b = a;
-    b.envs_per_block = perenv_envs_per_block(a.grid);
+    // about 8 KiB of layouts = 32 KiB of planes per workgroup (round 1: 16 KiB; 1M x 11x11 / 12x12, 512K x 18x18 with
+    // non-temporal stores: 107 / 125 / 134 us with 16 KiB, 102-103 / 120-122 / 133-140 with 8)
+    b.envs_per_block = perenv_envs_per_block(a.grid, 8192);
     const int64_t blocks = (a.n + b.envs_per_block - 1) / b.envs_per_block;
     if (!grid_ok(blocks)) return hipErrorInvalidConfiguration;
     hipLaunchKernelGGL((step_perenv_kernel<GT, VARIANT, DO_STEP>), dim3((unsigned)blocks), dim3(LMAZE_BLOCK),

@@ -89,6 +89,38 @@ def test_c5_1m_32x32_per_env_layouts():
     _check_invariants(env, bits)
 
 
+@pytest.mark.parametrize("variant,G,N", [("v0", 11, 460_000), ("v3", 12, 400_003), ("v0", 18, 170_001)])
+def test_per_env_lds_kernel_streaming_regime_against_the_oracle(variant, G, N):
+    """The LDS-tiled per-env kernel (every G whose G*G is not a multiple of 256) once its observation exceeds 192 MiB:
+    non-temporal stores, 8-KiB layout tiles, ragged last workgroup -- fused reset included, every step against the oracle."""
+    from helpers import bordered_random_layouts
+    lay_np = bordered_random_layouts(N, G, 900 + G)
+    env = PKG.LmazeVecEnv(N, variant=variant, per_env_layouts=torch.from_numpy(lay_np), seed=4, step_limit=5, env_base=77)
+    assert env.obs.numel() * 4 > (192 << 20)
+    st = {k: np.array(v, copy=True) for k, v in env.host_state().items()}
+    p = O.params(O.VARIANT_V3 if variant == "v3" else O.VARIANT_V0, G, O.LAYOUT_PER_ENV, env.step_limit, *env.rewards)
+    ref = np.zeros((N, G, G), np.int32)
+    rs = np.random.RandomState(G)
+    epoch = env._epoch
+    for t in range(8):
+        a = rs.randint(0, 5, N).astype(np.int32)
+        mask = np.ascontiguousarray(st["done"])
+        O.reset(p, lay_np, mask, 4, epoch, st["ball_xy"], st["goal_xy"] if variant == "v3" else None, st["step_count"],
+                st["reward"], st["done"], None, env_base=77)
+        epoch += 1
+        if variant == "v3":
+            O.step_v3(p, lay_np, a, st["ball_xy"], st["goal_xy"], st["step_count"], st["reward"], st["done"], ref)
+        else:
+            O.step_v0(p, lay_np, a, st["ball_xy"], st["step_count"], st["reward"], st["done"], st["goal_count"], ref)
+        obs, _, _, _ = env.step(torch.from_numpy(a), auto_reset=True)
+        h = env.host_state()
+        for k in ("ball_xy", "step_count", "done"):
+            assert (h[k] == st[k]).all(), (k, t)
+        assert (f32_bits(h["reward"]) == f32_bits(st["reward"])).all(), t
+        assert (_np(obs) == ref).all(), t
+    assert env._epoch == epoch
+
+
 @pytest.mark.parametrize("variant", ["v0", "v3"])
 def test_shard_equivalence(variant):
     """8 shards of N/8 (run one after another on this GPU) == one run of N: same reset draws
