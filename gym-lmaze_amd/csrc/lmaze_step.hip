@@ -801,7 +801,9 @@ static hipError_t launch_shared(const StepArgs& a, hipStream_t s) {
     // with the fused reset 78.8-84.6; the 64-env rows above are what launch_hint bits 10-11 = 1 selects.
     // launch_hint bits 0-3 / 4-7 override workgroups per CU / chunks per workgroup.
     int def_cu = 3, def_m = 2;
-    if (GT == 11) {
+    if (GT == 0) {
+        if (EPB == 16 || (EPB == 64 && a.grid < 12)) { def_cu = 5; def_m = 1; }
+    } else if (GT == 11) {
         if (EPB == 32) { def_cu = 8; def_m = 1; }
         else if (VARIANT == LMAZE_VARIANT_V3) { def_cu = 8; def_m = 1; }
         else if (a.auto_reset) { def_cu = 3; def_m = 2; }
@@ -955,9 +957,13 @@ static hipError_t launch_one(const StepArgs& a, int layout_mode, hipStream_t s) 
         if (sel == 0) sel = (DO_STEP && streaming) ? 2 : 1;
         if (sel == 2) return launch_shared<GT, VARIANT, DO_STEP, 4>(a, s);
         return launch_shared<GT, VARIANT, DO_STEP, 8>(a, s);
-    } else {  // unspecialised G: three sizes cover [3, 64]
-        if (a.grid >= 23) return launch_shared<GT, VARIANT, DO_STEP, 16>(a, s);
-        if (a.grid >= 12) return launch_shared<GT, VARIANT, DO_STEP, 64>(a, s);
+    } else {  // unspecialised G: three sizes cover [3, 64]; launch_hint bits 10-11: 1: 256, 2: 64, 3: 16 envs per workgroup
+        // Round 2 (1M envs at G = 9, 10, 13; 512K at 16, 20; 256K at 27; us per step, old -> new default): 64.9 -> 56.4,
+        // 88.0 -> 76.2, 120.7 (unchanged), 118.9 -> 90.0 (16 envs at (5, 2): 81.7), 169.7 -> 148.1, 155.3 -> 152.
+        int sel = (a.launch_hint >> 10) & 3;
+        if (sel == 0) sel = a.grid >= 15 ? 3 : (a.grid >= 5 ? 2 : 1);
+        if (sel == 3) return launch_shared<GT, VARIANT, DO_STEP, 16>(a, s);
+        if (sel == 2) return launch_shared<GT, VARIANT, DO_STEP, 64>(a, s);
         return launch_shared<GT, VARIANT, DO_STEP, 256>(a, s);
     }
 }

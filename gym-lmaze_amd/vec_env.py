@@ -285,7 +285,8 @@ class LmazeVecEnv(object):
     # launch policies autotune() tries: (workgroups per CU, chunks per workgroup) -> LmazeParams.launch_hint
     DEFAULT_POLICY = (0, 0)       # launch_hint = 0: the library's per-shape default (lmaze_step.hip launch_shared)
     # a third element selects the envs per workgroup where the kernel offers a choice (11x11, 12x12: 1 = 64, 2 = 32, 3 = 16;
-    # 14x14, 18x18: 1 = 32, 2 = 16; large 8x8 batches: 1 = 128, 2 = 64; 32x32: 1 = 8, 2 = 4)
+    # 14x14, 18x18: 1 = 32, 2 = 16; large 8x8 batches: 1 = 128, 2 = 64; 32x32: 1 = 8, 2 = 4; any other G: 1 = 256, 2 = 64,
+    # 3 = 16 -- include/lmaze.h)
     CANDIDATES = ((0, 0), (2, 1), (2, 2), (3, 1), (3, 2), (4, 1), (4, 2), (5, 2), (6, 2), (7, 2), (8, 1), (8, 2),
                   (6, 1, 2), (8, 1, 2), (5, 1, 2), (4, 2, 2), (3, 1, 2), (4, 1, 2), (3, 2, 2), (4, 1, 1), (3, 2, 1), (2, 1, 1), (2, 2, 1), (8, 1, 3), (5, 2, 3))
 
@@ -328,8 +329,6 @@ class LmazeVecEnv(object):
         if self.layout_mode != _abi.LAYOUT_SHARED or obs_bytes <= (192 << 20):
             return {}       # the knobs only pay in the streaming (non-temporal store) regime
         cands = [tuple(c) if isinstance(c, (tuple, list)) else (int(c), 1) for c in (candidates or self.CANDIDATES)]
-        if self.grid not in (8, 11, 12, 14, 18, 32):
-            cands = [c for c in cands if len(c) < 3]          # the selector only exists for those two sizes
         N = self.num_envs
         if actions is None:
             rows = max(2, min(512, (320 << 20) // (4 * N) + 1))          # > 256 MiB of action rows

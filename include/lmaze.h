@@ -86,7 +86,8 @@ typedef struct LmazeParams {
                             bits 4-7 = envs per wave (1: 64, 2: 32, 3: 16) and bits 0-3 = waves
                             per workgroup (1, 2, 4); bits 10-11 = envs per workgroup of the 11x11 /
                             12x12 kernels (1: 64, 2: 32, 3: 16; 0 = default) and of the 14x14 / 18x18 ones (1: 32,
-                            2: 16), of large 8x8 batches (1: 128, 2: 64) and of 32x32 (1: 8, 2: 4).  Performance only,
+                            2: 16), of large 8x8 batches (1: 128, 2: 64), of 32x32 (1: 8, 2: 4) and of any
+                            other G (1: 256, 2: 64, 3: 16).  Performance only,
                             never results (lmaze_step.hip launch_shared); other bits 0.      */
 } LmazeParams;
 
