@@ -918,7 +918,7 @@ static hipError_t launch_one(const StepArgs& a, int layout_mode, hipStream_t s) 
         // large 8x8 batches: launch_hint bits 10-11: 1: 128 envs per workgroup, 2: 64 (16 KiB of planes).  2M envs: 64 envs at
         // 4 / 5 / 6 / 8 per CU 89.0 / 91.7 / 91.8 / 91.7 us, 128 envs at (2, 1) 92.6, at 3-8 per CU 102-105.
         int sel = (a.launch_hint >> 10) & 3;
-        if (sel == 0) sel = (DO_STEP && a.obs != nullptr) ? 2 : 1;
+        if (sel == 0) sel = a.obs != nullptr ? 2 : 1;
         if (sel == 2) return launch_shared<GT, VARIANT, DO_STEP, 64>(a, s);
         return launch_shared<GT, VARIANT, DO_STEP, 128>(a, s);
     } else if constexpr (GT == 11 || GT == 12) {
@@ -932,8 +932,8 @@ static hipError_t launch_one(const StepArgs& a, int layout_mode, hipStream_t s) 
         // 12x12 (1M envs, 643 MB): 16 envs (9 KiB) per workgroup, uncapped 97.1-97.4 us, (5, 2) 96.0, against 104-105 for 64
         // envs at (2, 1) and 111-119 for nearly everything else; with the fused reset 103-104 against 109.  (3: 16 envs.)
         if (sel == 0) {
-            if (GT == 11) sel = (DO_STEP && streaming) ? 2 : 1;
-            else sel = (DO_STEP && streaming) ? 3 : 1;
+            if (GT == 11) sel = streaming ? 2 : 1;      // the render-only launches (lmaze_observe) write the same stream
+            else sel = streaming ? 3 : 1;
         }
         if (sel == 2) return launch_shared<GT, VARIANT, DO_STEP, 32>(a, s);
         if (sel == 3) return launch_shared<GT, VARIANT, DO_STEP, 16>(a, s);
@@ -945,7 +945,7 @@ static hipError_t launch_one(const StepArgs& a, int layout_mode, hipStream_t s) 
         // for 32 at (2, 1) -- but 118-134 one step to either side, so there it stays a tuner candidate.
         int sel = (a.launch_hint >> 10) & 3;
         const bool streaming = a.obs != nullptr && (size_t)a.n * GT * GT * 4 > kNonTemporalObsBytes;
-        if (sel == 0) sel = ((GT == 14 || VARIANT == LMAZE_VARIANT_V3) && DO_STEP && streaming) ? 2 : 1;   // v3 18x18 since its render went to bit strings: 16 envs at 4-5 per CU 109 us (with the fused reset 5-8 per CU 103-107) against 112-120
+        if (sel == 0) sel = ((GT == 14 || VARIANT == LMAZE_VARIANT_V3) && streaming) ? 2 : 1;   // v3 18x18 since its render went to bit strings: 16 envs at 4-5 per CU 109 us (with the fused reset 5-8 per CU 103-107) against 112-120
         if (sel == 2) return launch_shared<GT, VARIANT, DO_STEP, 16>(a, s);
         return launch_shared<GT, VARIANT, DO_STEP, 32>(a, s);
     } else if constexpr (GT == 32) {
@@ -954,7 +954,7 @@ static hipError_t launch_one(const StepArgs& a, int layout_mode, hipStream_t s) 
         // reset 4 envs at (5, 1) 88.6 / 342, at (6, 1) 81.8 / 313, against 102 / 403.
         int sel = (a.launch_hint >> 10) & 3;
         const bool streaming = a.obs != nullptr && (size_t)a.n * GT * GT * 4 > kNonTemporalObsBytes;
-        if (sel == 0) sel = (DO_STEP && streaming) ? 2 : 1;
+        if (sel == 0) sel = streaming ? 2 : 1;
         if (sel == 2) return launch_shared<GT, VARIANT, DO_STEP, 4>(a, s);
         return launch_shared<GT, VARIANT, DO_STEP, 8>(a, s);
     } else {  // unspecialised G: three sizes cover [3, 64]; launch_hint bits 10-11: 1: 256, 2: 64, 3: 16 envs per workgroup
