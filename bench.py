@@ -427,10 +427,6 @@ def main():
             # with a DIFFERENT kernel (the fill probe, same bytes per launch) so that under `rocprofv3 --stats` every
             # launch of the step kernel, warm-up included, is a warm one and the average is the timed policy's.
             warm_device(pkg, env.obs.numel() * 4, dev)
-            if args.launch_hint is not None and args.placement_trials > 1:
-                # a fixed policy still gets the placement trials of the tuned line it stands in for -- through the
-                # render-only kernel, so that no launch of the STEP kernel ever writes a buffer that is then dropped
-                env.place_observation_buffer(args.placement_trials)
 
         def run(k0, k, captured=False):
             for t in range(k0, k0 + k):

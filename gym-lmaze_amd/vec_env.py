@@ -406,42 +406,6 @@ class LmazeVecEnv(object):
         self.observe()
         return timings
 
-    def place_observation_buffer(self, trials=10, launches=12):
-        """Try `trials` allocations of the observation buffer and keep the one the RENDER-ONLY kernel (lmaze_observe, the
-        same store stream at the current launch_hint) fills fastest -- autotune(placement_trials=K) without a single
-        launch of the step kernel and without touching the state.  For a profiled process: the step kernel's
-        rocprofv3 --stats average then only covers launches on the buffer that is kept (bench.py --launch-hint).
-        Re-read `self.obs` afterwards.  Returns the trial times (ms)."""
-        obs_bytes = self.num_envs * self.grid * self.grid * 4
-        if self.layout_mode != _abi.LAYOUT_SHARED or obs_bytes <= (192 << 20) or int(trials) < 2:
-            return []
-        bufs = [self.obs] + [torch.empty_like(self.obs) for _ in range(int(trials) - 1)]
-        ms_of = []
-        with self._guard():
-            for b in bufs:
-                ptr = b.data_ptr()
-
-                def go(n):
-                    for _ in range(n):
-                        rc = _abi.lib.lmaze_observe(self._pp, self._p_layout, self._p_ball,
-                                                    self._p_goal if self._is_v3 else None, ptr, self.num_envs, self._stream())
-                        _abi.check("lmaze_observe", rc)
-                go(3)
-                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                e0.record()
-                go(int(launches))
-                e1.record()
-                e1.synchronize()
-                ms_of.append(e0.elapsed_time(e1) / int(launches))
-        keep = min(range(len(bufs)), key=lambda i: ms_of[i])
-        self.placement = {"trials_ms": [round(m, 5) for m in ms_of], "kept": keep, "probe": "lmaze_observe"}
-        self.obs = bufs[keep]
-        self._p_obs = self.obs.data_ptr()
-        self._expanded = None
-        del bufs
-        self.observe()
-        return ms_of
-
     def rollout(self, actions, auto_reset=True, device_epoch=False):
         """T steps over a device tensor int32[T,N] of actions, one kernel per step, no host
         sync (capture_rollout() records it into a hipGraph for launch-bound batch sizes).

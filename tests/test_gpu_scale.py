@@ -234,29 +234,6 @@ def test_autotune_placement_trials_rehome_the_observation_buffer_only():
     assert (env.expanded()[:64] == ref.expanded()[:64]).all()
 
 
-def test_place_observation_buffer_probes_with_the_render_only_kernel():
-    """place_observation_buffer(): the placement trials of autotune() without a launch of the step kernel and without
-    touching the state (bench.py --launch-hint under rocprofv3)."""
-    N = 1 << 19
-    env = PKG.LmazeVecEnv(N, variant="v0", layout=L.open_room(11), seed=9)
-    twin = PKG.LmazeVecEnv(N, variant="v0", layout=L.open_room(11), seed=9)
-    a = torch.randint(0, 4, (4, N), dtype=torch.int32, device="cuda")
-    env.step(a[0]); twin.step(a[0])
-    before = {k: np.array(v, copy=True) for k, v in env.host_state().items()}
-    env.params.launch_hint = PKG.LmazeVecEnv.launch_hint_of(5, 2)
-    ms = env.place_observation_buffer(trials=4, launches=3)
-    assert len(ms) == 4 and env.placement["probe"] == "lmaze_observe" and env.obs.data_ptr() == env._p_obs
-    after = env.host_state()
-    for k in before:
-        assert (before[k] == after[k]).all(), k
-    assert (env.obs == twin.obs).all()
-    for t in range(1, 4):
-        env.step(a[t]); twin.step(a[t])
-    assert (env.obs == twin.obs).all() and (env.ball_xy == twin.ball_xy).all()
-    small = PKG.LmazeVecEnv(1000, variant="v0", layout=L.open_room(11))
-    assert small.place_observation_buffer(trials=4) == []       # nothing to place below the streaming regime
-
-
 def test_episode_stats_match_numpy():
     N, G = 100003, 11
     lay = L.to_codes(L.open_room(G, (5, 5)))
