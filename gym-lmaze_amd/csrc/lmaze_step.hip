@@ -804,7 +804,9 @@ static hipError_t launch_shared(const StepArgs& a, hipStream_t s) {
     if (GT == 0) {
         if (EPB == 16 || (EPB == 64 && a.grid < 12)) { def_cu = 5; def_m = 1; }
     } else if (GT == 11) {
-        if (EPB == 32) { def_cu = 8; def_m = 1; }
+        // 32 envs: uncapped up to about 1.5M envs; from 2M on a cap pays (2M / 3M / 4M / 8M envs, us per step: (5, 1) 162 /
+        // 243 / 321 / 681 against 171 / 262 / 370 / 719 uncapped; 1.5M: 117 against 112)
+        if (EPB == 32) { def_cu = a.n >= ((int64_t)1 << 21) ? 5 : 8; def_m = 1; }
         else if (VARIANT == LMAZE_VARIANT_V3) { def_cu = 8; def_m = 1; }
         else if (a.auto_reset) { def_cu = 3; def_m = 2; }
         else { def_cu = 3; def_m = 1; }
