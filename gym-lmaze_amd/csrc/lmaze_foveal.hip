@@ -15,11 +15,11 @@
 #include "lmaze_common.h"
 
 // Timing decomposition (tools/foveal_decompose.py): a build with -DLMAZE_EXPERIMENT -- never the shipped
-// one -- reads bits 8-15 of launch_hint as switches that turn phases off (results are garbage then; only the time
+// one -- reads bits 16-23 of launch_hint as switches that turn phases off (results are garbage then; only the time
 // counts): 1 no set-up, 2 plain instead of non-temporal observation stores, 4 no observation stores, 8 no phase 1,
 // 16 stores as interleaved 4-KiB pieces, 32 no visit-map phase, 64 / 128 non-temporal visit-map stores / loads.
 #ifdef LMAZE_EXPERIMENT
-#define LMAZE_XP(args, mask) ((((args).p.launch_hint >> 8) & (mask)) != 0)
+#define LMAZE_XP(args, mask) ((((args).p.launch_hint >> 16) & (mask)) != 0)
 #else
 #define LMAZE_XP(args, mask) false
 #endif

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Where a foveal step launch spends its time: the experimental build (`make -C gym-lmaze_amd/csrc experiment`: csrc
-compiled with -DLMAZE_EXPERIMENT into tools/_exp/liblmaze_hip_exp.so, selected through LMAZE_HIP_LIB) can switch off the per-workgroup set-up (bit 8 of
-launch_hint), the observation stores (bit 10) and phase 1 (bit 11).  Results are garbage in those modes; only the
+compiled with -DLMAZE_EXPERIMENT into tools/_exp/liblmaze_hip_exp.so, selected through LMAZE_HIP_LIB) can switch off the per-workgroup set-up (bit 16 of
+launch_hint), the observation stores (bit 18) and phase 1 (bit 19).  Results are garbage in those modes; only the
 time counts.   LMAZE_HIP_LIB=tools/_exp/liblmaze_hip_exp.so python tools/foveal_decompose.py v2 v1"""
 import importlib
 import json
@@ -59,7 +59,7 @@ for variant in (sys.argv[1:] or ["v2", "v1"]):
             if True:
                 xp = modes[name]
                 env._state.copy_(snap)
-                env.params.launch_hint = (xp << 8) | (epb << 4) | cap
+                env.params.launch_hint = (xp << 16) | (epb << 4) | cap
                 run(3)
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 e0.record()
