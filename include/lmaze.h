@@ -77,18 +77,23 @@ typedef struct LmazeParams {
     float reward_wall;   /* negativeNominal  -1.0   (v0:21)                                  */
     float reward_move;   /* positiveNominal  -0.01  (v0:22)                                  */
     float reward_goal;   /* positiveFull    100.0   (v0:23)                                  */
-    int32_t launch_hint; /* 0 = library default launch policy; else bits 0-3 = workgroups per
-                            CU (1..8, 0 = default), bits 4-7 = chunks of envs a workgroup
-                            takes one after the other, loading the next chunk's inputs while
-                            it stores the current one (1..15, 0 = default); bit 8 = keep the
-                            workgroup/LDS kernel where the library would pick the wave-autonomous
-                            one (8x8 shared layouts whose planes stay on-die); for that kernel
-                            bits 4-7 = envs per wave (1: 64, 2: 32, 3: 16) and bits 0-3 = waves
-                            per workgroup (1, 2, 4); bits 10-11 = envs per workgroup of the 11x11 /
-                            12x12 kernels (1: 64, 2: 32, 3: 16; 0 = default) and of the 14x14 / 18x18 ones (1: 32,
-                            2: 16), of large 8x8 batches (1: 128, 2: 64), of 32x32 (1: 8, 2: 4) and of any
-                            other G (1: 256, 2: 64, 3: 16).  Performance only,
-                            never results (lmaze_step.hip launch_shared); other bits 0.      */
+    int32_t launch_hint; /* 0 = library default launch policy.  Performance only, never results
+                            (lmaze_step.hip launch_shared / launch_one); bits not listed are 0.
+                              bits 0-3   workgroups resident per CU (1..8; 0 = default)
+                              bits 4-7   chunks of envs a workgroup takes one after the other, loading
+                                         the next chunk's inputs while it stores the current one
+                                         (1..15; 0 = default)
+                              bit  8     keep the workgroup/LDS kernel where the library would pick the
+                                         wave-autonomous one (8x8 shared layouts whose planes stay
+                                         on-die); for the wave-autonomous kernel bits 4-7 = envs per
+                                         wave (1: 64, 2: 32, 3: 16), bits 0-3 = waves per workgroup
+                                         (1, 2, 4)
+                              bits 10-11 envs per workgroup (0 = default):
+                                           11x11, 12x12        1: 64   2: 32   3: 16
+                                           14x14, 18x18        1: 32   2: 16
+                                           8x8 (large batch)   1: 128  2: 64
+                                           32x32               1: 8    2: 4
+                                           any other G         1: 256  2: 64   3: 16                     */
 } LmazeParams;
 
 int lmaze_abi_version(void);
