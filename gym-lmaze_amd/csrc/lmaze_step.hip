@@ -811,7 +811,7 @@ static hipError_t launch_shared(const StepArgs& a, hipStream_t s) {
         else if (a.auto_reset) { def_cu = 3; def_m = 2; }
         else { def_cu = 3; def_m = 1; }
     } else if (GT == 32 && EPB == 4) {
-        def_cu = 5; def_m = 1;
+        def_cu = a.auto_reset ? 6 : 5; def_m = 1;
     } else if (GT == 8 && EPB == 64) {
         def_cu = 4; def_m = 1;
     } else if (GT == 14 && EPB == 16) {
