@@ -818,10 +818,11 @@ static hipError_t launch_shared(const StepArgs& a, hipStream_t s) {
         def_cu = 5; def_m = VARIANT == LMAZE_VARIANT_V3 ? 2 : 1;     // v3 (bit-string render): (5, 2) 127 us, (5, 1) 150
     } else if (GT == 12 && EPB == 16) {
         def_cu = 8; def_m = 1;
+        if (a.auto_reset) { def_cu = 5; def_m = 2; }               // fused reset: (5, 2) 92.7-93.8 us on three boxes, (8, 1) 103-107
     } else if (GT == 8 || GT == 12 || GT == 14) {
         def_cu = 2; def_m = 1;
     } else if (GT == 18 && EPB == 16) {
-        def_cu = 5; def_m = 1;
+        def_cu = a.auto_reset ? 6 : 5; def_m = 1;                   // fused reset: 6-8 per CU 102.5-104 us on three boxes, 5 per CU 107-109
     } else if (GT == 18) {
         def_cu = 2; def_m = a.auto_reset ? 2 : 1;
     } else if (GT == 32) {
