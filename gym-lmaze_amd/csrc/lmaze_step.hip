@@ -802,7 +802,10 @@ static hipError_t launch_shared(const StepArgs& a, hipStream_t s) {
     // launch_hint bits 0-3 / 4-7 override workgroups per CU / chunks per workgroup.
     int def_cu = 3, def_m = 2;
     if (GT == 0) {
-        if (EPB == 16 || (EPB == 64 && a.grid < 12)) { def_cu = 5; def_m = 1; }
+        // profiles/r02/shape_sweep.jsonl (G = 9, 10, 13, 16, 20, 24, 27): 16 envs (5, 2) beats (5, 1) by 2-9 %, with the
+        // fused reset (8, 2) by 3-22 %; 64 envs below G = 12: (5, 1), fused reset (5, 2)
+        if (EPB == 16) { def_cu = a.auto_reset ? 8 : 5; def_m = 2; }
+        else if (EPB == 64 && a.grid < 12) { def_cu = 5; def_m = a.auto_reset ? 2 : 1; }
     } else if (GT == 11) {
         // 32 envs: uncapped up to about 1.5M envs; from 2M on a cap pays (2M / 3M / 4M / 8M envs, us per step: (5, 1) 162 /
         // 243 / 321 / 681 against 171 / 262 / 370 / 719 uncapped; 1.5M: 117 against 112)
