@@ -439,7 +439,7 @@ def main():
         run(0, args.warmup)
         torch.cuda.synchronize()
         if hier:       # the event counts of the timed steps come from a replay of exactly these steps (below)
-            snap = (env._state.clone(), env.visit.clone(), env._epoch)
+            snap = env.snapshot()
         if dist is not None:
             dist.barrier()
         torch.cuda.synchronize()
@@ -490,7 +490,7 @@ def main():
     if hier and rank == 0:
         # replay the timed steps from the snapshot (same actions, goals and epochs => the same trajectory) and count
         # the events the algorithmic bytes depend on; untimed
-        env._state.copy_(snap[0]); env.visit.copy_(snap[1]); env._epoch = snap[2]
+        env.restore(snap)
         cnt = torch.zeros(5, dtype=torch.int64, device=dev)
         with torch.cuda.device(dev):
             for t in range(args.warmup, args.warmup + args.steps):

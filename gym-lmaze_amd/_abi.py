@@ -16,7 +16,7 @@ import torch  # noqa: F401
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("LMAZE_HIP_LIB") or os.path.join(HERE, "liblmaze_hip.so")   # override: another build of the same ABI
 
-ABI_VERSION = 3
+ABI_VERSION = 4
 VARIANT_V0, VARIANT_V3 = 0, 3
 VARIANT_V1, VARIANT_V2, VARIANT_V4, VARIANT_V5, VARIANT_V6 = 1, 2, 4, 5, 6
 FOVEA = 5
@@ -29,7 +29,8 @@ MAX_GRID, MAX_CHANNELS = 64, 8
 SYMBOLS = ("lmaze_abi_version", "lmaze_strerror", "lmaze_device_info", "lmaze_step_v0", "lmaze_step_v3",
            "lmaze_step_v0_autoreset", "lmaze_step_v3_autoreset", "lmaze_observe", "lmaze_reset",
            "lmaze_episode_stats", "lmaze_bandwidth_probe", "lmaze_render_expanded", "lmaze_foveal_step", "lmaze_foveal_step_autoreset", "lmaze_foveal_reset", "lmaze_v1_set_foveal_goal",
-           "lmaze_v5_planner_step", "lmaze_v5_hier_step", "lmaze_v6_safe_foveal_goal", "lmaze_expand_planes")
+           "lmaze_v5_planner_step", "lmaze_v5_hier_step", "lmaze_v6_safe_foveal_goal", "lmaze_expand_planes",
+           "lmaze_foveal_visit_bytes", "lmaze_foveal_materialise_visit", "lmaze_foveal_load_visit")
 
 
 class LmazeParams(C.Structure):
@@ -48,7 +49,7 @@ class LmazeFovealParams(C.Structure):
 
 FOVEAL_BUFFER_FIELDS = ("ball_xy", "goal_xy", "fgoal_xy", "layout_id", "step_count", "foveal_step_count",
                         "reward", "foveal_reward", "done", "foveal_done", "visit", "obs",
-                        "ball1_xy", "fovea_xy", "last_xy", "foveal_goal", "obs_local")
+                        "ball1_xy", "fovea_xy", "last_xy", "foveal_goal", "obs_local", "visit_clock")
 
 
 class LmazeFovealBuffers(C.Structure):
@@ -129,6 +130,12 @@ def _load():
     lib.lmaze_v6_safe_foveal_goal.argtypes = [FP, vp, u64, u64, i64, FB, vp, i64, vp]
     lib.lmaze_expand_planes.restype = C.c_int
     lib.lmaze_expand_planes.argtypes = [vp, i32, i32, i32, vp, i64, vp]
+    lib.lmaze_foveal_visit_bytes.restype = i64
+    lib.lmaze_foveal_visit_bytes.argtypes = [i32, i64]
+    lib.lmaze_foveal_materialise_visit.restype = C.c_int
+    lib.lmaze_foveal_materialise_visit.argtypes = [FP, FB, vp, i64, vp]
+    lib.lmaze_foveal_load_visit.restype = C.c_int
+    lib.lmaze_foveal_load_visit.argtypes = [FP, FB, vp, i64, vp]
     if lib.lmaze_abi_version() != ABI_VERSION:
         raise ImportError("liblmaze_hip.so ABI %d != binding %d: rebuild" % (lib.lmaze_abi_version(), ABI_VERSION))
     return lib

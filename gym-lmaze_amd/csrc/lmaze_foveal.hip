@@ -9,10 +9,12 @@
 // Same two-phase shape as lmaze_step.hip: one lane per env runs the transition against the
 // layout table held in LDS and leaves the env's observation in LDS as 25-bit plane masks; then the
 // workgroup's lanes stripe its contiguous observation range float[envs*C*25] with 16-byte stores.
-// v4-v6 add a middle phase: the visit maps float[envs*G*G] that change are streamed through (load,
-// + window, halve, store) with 16-byte accesses, keeping the cells the windows show in LDS.
-// HBM bytes per env-step: v1 454, v2 545, v4 3 337.
+// v4-v6 add a middle phase on the visit map, kept CLOCK-RELATIVE and TILED (include/lmaze.h "The visit map"): the
+// reference halves the whole G x G plane on every update (v4:211-214, v5:313-318); here that is `clock += 1` and a
+// step only gathers the 2 x 2 tiles (4 x 4 cells, 64 B each) under the window it shows, adds, and writes them back.
+// HBM bytes per env-step: v1 454, v2 545, v4 about 1 000 instead of round 2's 3 337.
 #include "lmaze_common.h"
+#include "lmaze_visit.h"
 
 // Timing decomposition (tools/foveal_decompose.py): a build with -DLMAZE_EXPERIMENT -- never the shipped
 // one -- reads bits 16-23 of launch_hint as switches that turn phases off (results are garbage then; only the time
@@ -164,6 +166,15 @@ __device__ __forceinline__ void nibble_floats(const uint32_t* bits, int q, float
     for (int k = 0; k < 4; ++k) v[k] = __uint_as_float((0u - ((nib >> k) & 1u)) & 0x3f800000u);
 }
 
+// The visit map in its clock-relative frame: the bit-pattern arithmetic lives in lmaze_visit.h (shared with the host-side
+// property test of the CPU suite); here only the tile geometry.
+constexpr int VISIT_BIAS = LMAZE_VISIT_BIAS, VISIT_RENORM = LMAZE_VISIT_RENORM;
+constexpr int VT = 4;                // tile side; a tile is 16 floats = 64 bytes
+
+__host__ __device__ __forceinline__ int visit_tiles(int G) { return (G + VT - 1) / VT; }
+__device__ __forceinline__ uint32_t visit_true(uint32_t bits, int E) { return lmaze_visit_true(bits, E); }
+__device__ __forceinline__ uint32_t visit_add(uint32_t bits, int E) { return lmaze_visit_add(bits, E); }
+
 // GT = grid side known at compile time (14 and 18, the reference's sizes; 0: read it from the params):
 // the visit-map stream divides by G for every cell, which is only cheap with a constant
 // AR = fused auto-reset compiled in (a separate instantiation: the extra state it threads through the
@@ -187,14 +198,16 @@ __global__ __launch_bounds__(LMAZE_BLOCK) void foveal_kernel(const FovealArgs a)
     int32_t* flags = reinterpret_cast<int32_t*>(cen + EPB * 4);            // [EPB]     bit0 skip, bit1 visit update, bit2 fresh episode, bit3 not stepped
     int16_t* rcen = reinterpret_cast<int16_t*>(flags + EPB);               // [EPB][2]  ball a fused reset placed (visit map re-init)
     float* vwin = reinterpret_cast<float*>(rcen + EPB * 2);                // [EPB][2][25] visit-map samples (v4-v6)
-    uint64_t* rowfree = reinterpret_cast<uint64_t*>(vwin + (V4 ? EPB * 2 * W25 : 0));  // [L*G] free = B|S|X
+    int32_t* clk = reinterpret_cast<int32_t*>(vwin + (V4 ? EPB * 2 * W25 : 0));   // [EPB] visit clock on entry (v4-v6)
+    int32_t* dlist = clk + (V4 ? EPB : 0);                                 // [EPB] envs whose whole map is rewritten this call
+    uint64_t* rowfree = reinterpret_cast<uint64_t*>(dlist + (V4 ? EPB : 0));   // [L*G] free = B|S|X
     uint64_t* rowgoal = rowfree + L * G;                                   // [L*G] interior, not 'W', not 'S' (v2:279)
     uint64_t* rowball = rowgoal + L * G;                                   // [L*G] interior, not 'W', not 'X' (v2:292)
     uint64_t* rowwall = rowball + L * G;                                   // [G] v1: 'W'
     uint64_t* rowx = rowwall + G;                                          // [G] v1: 'X'
     uint8_t* lays = reinterpret_cast<uint8_t*>(rowx + G);                  // [L*CELLS]
     static_assert(PERENV <= 8 * 32 - 32 && 4 * W25 <= 4 * 32 - 4, "bit strings fit the 32 B / 16 B per env reserved for them");
-    __shared__ int any_skip;
+    __shared__ int any_skip, ndense;
 
     const int tid = threadIdx.x;
     // A workgroup takes chunks of EPB envs grid-stride (chunk = blockIdx.x, + gridDim.x, ...; one chunk each unless the
@@ -204,7 +217,7 @@ __global__ __launch_bounds__(LMAZE_BLOCK) void foveal_kernel(const FovealArgs a)
     int64_t chunk = blockIdx.x;
     int64_t blockbase = chunk * EPB;
     int nb = (int)min((int64_t)EPB, a.n - blockbase);
-    if (tid == 0) any_skip = 0;
+    if (tid == 0) { any_skip = 0; ndense = 0; }
     for (int i = tid; i < EPB * 12; i += LMAZE_BLOCK) obits[i] = 0u;       // obits and lbits
     // the reset epoch, read in front of every store (one uniform scalar load; lmaze_step.hip step_shared_kernel)
     const uint64_t epoch = launch_epoch(a.epoch, a.epoch_in);
@@ -314,6 +327,7 @@ __global__ __launch_bounds__(LMAZE_BLOCK) void foveal_kernel(const FovealArgs a)
         bool fresh = false, nostep = false;   // fused reset: new episode this call / its step was refused
         int rx = 0, ry = 0;                   // ball the fused reset placed
         int bx = a.b.ball_xy[2 * e], by = a.b.ball_xy[2 * e + 1];
+        const int vclock = (V4 && !(V5 && MODE == FM_PLANNER)) ? a.b.visit_clock[e] : 0;
         r.px = (int16_t)bx; r.py = (int16_t)by;
         if (MODE != FM_STEP && a.mask && !a.mask[e]) r.skip = 1;
         if (V1) {
@@ -617,7 +631,25 @@ __global__ __launch_bounds__(LMAZE_BLOCK) void foveal_kernel(const FovealArgs a)
                 if (!(V4 && (ch == 2 || ch == 6))) put_bits(obits, le * PERENV + ch * W25, m[ch]);
         }
         cen[le * 4 + 0] = r.cx; cen[le * 4 + 1] = r.cy; cen[le * 4 + 2] = r.px; cen[le * 4 + 3] = r.py;
-        flags[le] = (r.skip ? 1 : 0) | (r.upd ? 2 : 0) | (fresh ? 4 : 0) | (nostep ? 8 : 0);
+        int fl = (r.skip ? 1 : 0) | (r.upd ? 2 : 0) | (fresh ? 4 : 0) | (nostep ? 8 : 0);
+        if (V4 && !(V5 && MODE == FM_PLANNER) && !r.skip) {
+            // What this call does to the env's visit map, in clock terms (phase 2 carries it out on the cells):
+            //   zero    reset(): the map restarts from zeros, clock 0 (v4:112, v5:130)
+            //   renorm  the clock is about to leave the exponent range: rewrite the map in true values, clock VISIT_BIAS
+            //   pre     fused reset of v4: the reset's own (0 + window) / 2 at the placed ball (v4:116-119)
+            //   add     this call's (map + window) / 2 at the window centre: v4 every step and every reset
+            //           (v4:211-214), v5/v6 only on localDone (v5:313-318) and never at reset (v5:130)
+            const bool zero = MODE == FM_RESET || (MODE == FM_STEP && AR && fresh);
+            const bool renorm = !zero && vclock >= VISIT_RENORM;
+            const bool pre = !V5 && MODE == FM_STEP && AR && fresh;
+            const bool add = !(V5 && MODE == FM_RESET) && !nostep && !(V5 && MODE == FM_STEP && !r.upd);
+            fl |= (zero ? 16 : 0) | (renorm ? 32 : 0) | (pre ? 64 : 0) | (add ? 128 : 0);
+            const int c1 = (zero ? 0 : (renorm ? VISIT_BIAS : vclock)) + (pre ? 1 : 0) + (add ? 1 : 0);
+            if (c1 != vclock) a.b.visit_clock[e] = c1;
+            if (zero || renorm) dlist[atomicAdd(&ndense, 1)] = le;
+        }
+        if (V4) clk[le] = vclock;
+        flags[le] = fl;
         rcen[le * 2] = (int16_t)rx; rcen[le * 2 + 1] = (int16_t)ry;
         if (r.skip) any_skip = 1;
     }
@@ -625,131 +657,138 @@ __global__ __launch_bounds__(LMAZE_BLOCK) void foveal_kernel(const FovealArgs a)
     const bool some_skipped = any_skip != 0;
 
     // ---------------- phase 2 (v4-v6): the visit maps, v4:116-119 / v4:211-214 / v5:313-318 ----------------
-    // Envs whose map changes are streamed through (load, + window, halve, store; 16-byte accesses, UNR loads in
-    // flight per lane) and the cells that fall in their two observation windows are kept in LDS on the way; envs
-    // whose map does not change (v5/v6 without localDone) only have those 2 x 25 cells gathered, one lane per
-    // window row.  Every byte of a map is read and written at most once per launch.
+    // Clock-relative tiles (include/lmaze.h "The visit map"): the whole-plane halving already happened in phase 1 (the
+    // env's clock moved); what is left is the 5x5 window.  Every env gathers the 2 x 2 tiles under its current window
+    // and the 2 x 2 under the "previous" one (those it does not share with the first), one lane per tile row (16 B),
+    // every load of the workgroup in flight before the first is used; cells inside the current window take
+    // (v + 1) / 2 when the map updates this call, the tiles go back whole (64-byte sectors, no partial writes), and the
+    // two windows' TRUE values -- the "previous" one sampled live from the updated map, Appendix B-7 -- are left in
+    // LDS for phase 3.  The few envs whose whole map is rewritten (reset: zeros; clock at VISIT_RENORM: true values)
+    // are streamed tile by tile after that.
     if (V4 && !(V5 && MODE == FM_PLANNER) && !LMAZE_XP(a, 32)) {
-        float* vis = a.b.visit + (size_t)blockbase * CELLS;
-        const int total = nb * CELLS;
-        // One cell: v <- (v + [cell in the 5x5 window at (cx, cy)]) / 2 when `add` -- float32 add + exact halving ==
-        // the reference's float64 round trip -- and, when `le` >= 0, the new value goes to the env's window samples
-        // if the current window (centre cx, cy: the window just added) or the "previous" one (px, py) shows the cell.
-        auto cell = [&](float v, int x, int y, int cx, int cy, bool add, int le, int px, int py) -> float {
-            const int dx = x - cx + 2, dy = y - cy + 2;
-            const bool in = (unsigned)dx <= 4u && (unsigned)dy <= 4u;
-            if (add) v = (v + (in ? 1.0f : 0.0f)) * 0.5f;
-            if (le >= 0) {
-                if (in) vwin[le * 2 * W25 + dx * FOV + dy] = v;
-                const int ex = x - px + 2, ey = y - py + 2;
-                if ((unsigned)ex <= 4u && (unsigned)ey <= 4u) vwin[le * 2 * W25 + W25 + ex * FOV + ey] = v;
-            }
-            return v;
-        };
-        auto update4 = [&](float4& v, int c0, int cx, int cy, bool add, int le, int px, int py) {
-            int x = c0 / G, y = c0 - x * G;
-            float* p = &v.x;
+        const int TB = visit_tiles(G), TILES = TB * TB;
+        uint32_t* vis = reinterpret_cast<uint32_t*>(a.b.visit) + (size_t)blockbase * TILES * (VT * VT);
+        // One tile row of a GATHERED tile: cells (x, y0 .. y0 + 3) of env le, stored values in s[].  A cell inside the
+        // current window takes (v + 1) / 2 when the map updates this call (`add`); the true values of the cells the two
+        // windows show -- under the clock the call ends with -- go to vwin.  One decode per cell, none for cells outside
+        // both windows.
+        auto tile_row = [&](uint32_t (&s)[4], int x, int y0, int le, bool add) {
+            const int E0 = clk[le];
+            const int dx = x - cen[le * 4] + 2, ex = x - cen[le * 4 + 2] + 2;
+            const int dy0 = y0 - cen[le * 4 + 1] + 2, ey0 = y0 - cen[le * 4 + 3] + 2;
+            const bool rowc = x < G && (unsigned)dx <= 4u, rowp = x < G && (unsigned)ex <= 4u;
+            if (!rowc && !rowp) return;
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
-                p[k] = cell(p[k], x, y, cx, cy, add, le, px, py);
-                if (++y == G) { y = 0; ++x; }
+                const bool in = rowc && (unsigned)(dy0 + k) <= 4u && y0 + k < G;
+                const bool inp = rowp && (unsigned)(ey0 + k) <= 4u && y0 + k < G;
+                if (!in && !inp) continue;
+                const bool upd = in && add;
+                uint32_t t = visit_true(s[k], upd ? E0 : E0 + (add ? 1 : 0));
+                if (upd) {
+                    const float w = (__uint_as_float(t) + 1.0f) * 0.5f;       // v4:214; see visit_add
+                    t = __float_as_uint(w);
+                    s[k] = lmaze_visit_store(w, E0 + 1);
+                }
+                if (in) vwin[le * 2 * W25 + dx * FOV + dy0 + k] = __uint_as_float(t);
+                if (inp) vwin[le * 2 * W25 + W25 + ex * FOV + ey0 + k] = __uint_as_float(t);
+            }
+        };
+        // The same for an env whose WHOLE map is rewritten this call: zeros (reset) or true values (clock at
+        // VISIT_RENORM) first, then the fused reset's own window at the placed ball (`pre`, v4:116-119), then `add`.
+        auto tile_row_whole = [&](uint32_t (&s)[4], int x, int y0, int le, int fl) {
+            const int E0 = clk[le];
+            const bool zero = fl & 16, renorm = fl & 32, pre = fl & 64, add = fl & 128;
+            const int cx = cen[le * 4], cy = cen[le * 4 + 1], px = cen[le * 4 + 2], py = cen[le * 4 + 3];
+            const int E1 = zero ? 0 : (renorm ? VISIT_BIAS : E0);
+            const int dx = x - cx + 2, ex = x - px + 2;
+#pragma unroll 1
+            for (int k = 0; k < 4; ++k) {
+                const int y = y0 + k;
+                const bool cell_ok = x < G && y < G;      // tiles are padded up to a multiple of 4: those cells stay 0
+                uint32_t b = s[k];
+                if (zero) b = 0u;
+                else if (renorm) b = visit_true(b, E0);
+                int E = E1;
+                if (pre) {
+                    const int qx = x - rcen[le * 2] + 2, qy = y - rcen[le * 2 + 1] + 2;
+                    if (cell_ok && (unsigned)qx <= 4u && (unsigned)qy <= 4u) b = visit_add(b, E);
+                    ++E;
+                }
+                const int dy = y - cy + 2, ey = y - py + 2;
+                const bool in = cell_ok && (unsigned)dx <= 4u && (unsigned)dy <= 4u;
+                if (add) {
+                    if (in) b = visit_add(b, E);
+                    ++E;
+                }
+                s[k] = b;
+                if (in) vwin[le * 2 * W25 + dx * FOV + dy] = __uint_as_float(visit_true(b, E));
+                if (cell_ok && (unsigned)ex <= 4u && (unsigned)ey <= 4u)
+                    vwin[le * 2 * W25 + W25 + ex * FOV + ey] = __uint_as_float(visit_true(b, E));
             }
         };
         // window cells outside the array read 0 (the padded layouts never get there)
         for (int i = tid; i < nb * 2 * W25; i += LMAZE_BLOCK) vwin[i] = 0.0f;
         __syncthreads();
-        if ((CELLS & 3) == 0) {  // a 16-byte access never straddles two envs
-            // UNR independent loads in flight per lane before the first is used: with one load -> update -> store
-            // round trip at a time a wave lived 66 us (20 trips of ~3 us under load), 75 % of it in s_waitcnt
-            constexpr int UNR = 4;
-            const int nq4 = total >> 2;
-            for (int q0 = tid; q0 < nq4; q0 += UNR * LMAZE_BLOCK) {
-                float4 v[UNR];
-                int les[UNR], c0s[UNR], fls[UNR];
-                bool act[UNR];
+        {
+            // item = (env, set 0: current window / 1: "previous" window, tile 0..3 of the 2 x 2, row 0..3 of the tile)
+            constexpr int UNR = 4, IPE = 2 * 4 * VT;
+            const int items = nb * IPE;
+            for (int i0 = tid; i0 < items; i0 += UNR * LMAZE_BLOCK) {
+                uint4 v[UNR];
+                int off[UNR], meta[UNR];     // meta: env | x << 8 | y << 15 | set << 22 | flags << 24
 #pragma unroll
                 for (int u = 0; u < UNR; ++u) {
-                    const int q = q0 + u * LMAZE_BLOCK;
-                    const int f0 = q << 2;
-                    les[u] = f0 / CELLS;
-                    c0s[u] = f0 - les[u] * CELLS;
-                    fls[u] = q < nq4 ? flags[les[u]] : 1;
-                    const bool fresh = MODE == FM_STEP && AR && (fls[u] & 4);
-                    act[u] = !(fls[u] & 1) && !(V5 && MODE == FM_STEP && !(fls[u] & 2) && !fresh);   // else: map unchanged
-                }
-#pragma unroll
-                for (int u = 0; u < UNR; ++u) {
-                    v[u] = make_float4(0.f, 0.f, 0.f, 0.f);                 // reset: v4:112 / v5:130
-                    // the few freshly reset maps of a fused step are loaded too and drop what they read (a load that
-                    // waits on more than the skip / update flag does not pipeline)
-                    if (MODE == FM_STEP && act[u]) {
-                        if (LMAZE_XP(a, 128)) {
-                            typedef float v4f __attribute__((ext_vector_type(4)));
-                            const v4f t = __builtin_nontemporal_load(reinterpret_cast<const v4f*>(vis) + q0 + u * LMAZE_BLOCK);
-                            v[u] = make_float4(t.x, t.y, t.z, t.w);
-                        } else {
-                            v[u] = reinterpret_cast<const float4*>(vis)[q0 + u * LMAZE_BLOCK];
-                        }
-                    }
-                }
-#pragma unroll
-                for (int u = 0; u < UNR; ++u) {
-                    if (!act[u]) continue;
-                    const int le = les[u], c0 = c0s[u], fl = fls[u];
-                    const bool upd = fl & 2;
-                    const bool fresh = MODE == FM_STEP && AR && (fl & 4), nostep = MODE == FM_STEP && AR && (fl & 8);
-                    if (fresh) {                                            // fused reset: v4:112-119 at the placed ball
-                        v[u] = make_float4(0.f, 0.f, 0.f, 0.f);
-                        if (!V5) update4(v[u], c0, rcen[le * 2], rcen[le * 2 + 1], true, -1, 0, 0);   // v5:130 restarts from zeros, no window
-                    }
-                    const bool add = !(V5 && MODE == FM_RESET) && !nostep && !(V5 && MODE == FM_STEP && !upd);   // v5 adds no window at reset
-                    update4(v[u], c0, cen[le * 4], cen[le * 4 + 1], add, le, cen[le * 4 + 2], cen[le * 4 + 3]);
-                    if (LMAZE_XP(a, 64)) {
-                        typedef float v4f __attribute__((ext_vector_type(4)));
-                        const v4f t = {v[u].x, v[u].y, v[u].z, v[u].w};
-                        __builtin_nontemporal_store(t, reinterpret_cast<v4f*>(vis) + q0 + u * LMAZE_BLOCK);
+                    const int i = i0 + u * LMAZE_BLOCK;
+                    const int le = i / IPE, r = i - le * IPE;
+                    const int set = r >> 4, t = (r >> 2) & 3, row = r & 3;
+                    off[u] = -1;
+                    meta[u] = 0;
+                    if (i >= items) continue;
+                    const int fl = flags[le];
+                    if (fl & (1 | 16 | 32)) continue;                       // untouched, or rewritten whole below
+                    const int ta = (cen[le * 4] - 2) >> 2, tb = (cen[le * 4 + 1] - 2) >> 2;   // first tile row / column of the current window
+                    int tx, ty;
+                    if (set == 0) {
+                        tx = ta + (t >> 1); ty = tb + (t & 1);
                     } else {
-                        reinterpret_cast<float4*>(vis)[q0 + u * LMAZE_BLOCK] = v[u];
+                        tx = ((cen[le * 4 + 2] - 2) >> 2) + (t >> 1); ty = ((cen[le * 4 + 3] - 2) >> 2) + (t & 1);
+                        if ((unsigned)(tx - ta) <= 1u && (unsigned)(ty - tb) <= 1u) continue;   // the current window's item has it
                     }
+                    if ((unsigned)tx >= (unsigned)TB || (unsigned)ty >= (unsigned)TB) continue;
+                    off[u] = (le * TILES + tx * TB + ty) * (VT * VT) + row * VT;
+                    meta[u] = le | ((tx * VT + row) << 8) | ((ty * VT) << 15) | (set << 22) | ((fl & 0xff) << 24);
                 }
-            }
-        } else {
-            for (int f = tid; f < total; f += LMAZE_BLOCK) {
-                const int le = f / CELLS;
-                const int c = f - le * CELLS;
-                const int fl = flags[le];
-                const bool skip = fl & 1, upd = fl & 2;
-                const bool fresh = MODE == FM_STEP && AR && (fl & 4), nostep = MODE == FM_STEP && AR && (fl & 8);
-                if (skip || (V5 && MODE == FM_STEP && !upd && !fresh)) continue;
-                const int x = c / G, y = c - x * G;
-                float v = (MODE == FM_STEP && !fresh) ? vis[f] : 0.0f;
-                if (fresh && !V5) v = cell(v, x, y, rcen[le * 2], rcen[le * 2 + 1], true, -1, 0, 0);
-                const bool add = !(V5 && MODE == FM_RESET) && !nostep && !(V5 && MODE == FM_STEP && !upd);
-                v = cell(v, x, y, cen[le * 4], cen[le * 4 + 1], add, le, cen[le * 4 + 2], cen[le * 4 + 3]);
-                vis[f] = v;
+#pragma unroll
+                for (int u = 0; u < UNR; ++u)
+                    if (off[u] >= 0) v[u] = *reinterpret_cast<const uint4*>(vis + off[u]);
+#pragma unroll
+                for (int u = 0; u < UNR; ++u) {
+                    if (off[u] < 0) continue;
+                    uint32_t sv[4] = {v[u].x, v[u].y, v[u].z, v[u].w};
+                    const int fl = (meta[u] >> 24) & 0xff;
+                    tile_row(sv, (meta[u] >> 8) & 127, (meta[u] >> 15) & 127, meta[u] & 255, (fl & 128) != 0);
+                    if ((fl & 128) && !((meta[u] >> 22) & 1))             // the map updated: the current window's tiles go back
+                        *reinterpret_cast<uint4*>(vis + off[u]) = make_uint4(sv[0], sv[1], sv[2], sv[3]);
+                }
             }
         }
-        if (V5 && MODE == FM_STEP) {
-            // unchanged maps: the two windows straight from HBM, one lane per window row (5 adjacent floats, 2 load
-            // instructions; the per-element gather of round 1 made this phase 40 % of a v5 launch)
-            for (int i = tid; i < nb * 2 * FOV; i += LMAZE_BLOCK) {
-                const int le = i / (2 * FOV);
-                if (flags[le] & (AR ? 7 : 3)) continue;     // skipped, streamed, or freshly zeroed (kept by the stream)
-                const int r = i - le * 2 * FOV;
-                const int w = r / FOV, row = r - w * FOV;
-                const int x = cen[le * 4 + 2 * w] - 2 + row, y0 = cen[le * 4 + 2 * w + 1] - 2;
-                if (x < 0 || x >= G) continue;              // outside the array: stays 0
-                const float* src = vis + (size_t)le * CELLS + x * G;
-                float* dst = vwin + le * 2 * W25 + w * W25 + row * FOV;
-                if (y0 >= 0 && y0 + FOV <= G) {
-                    struct __attribute__((packed, aligned(4))) Row5 { float v[FOV]; };
-                    const Row5 t = *reinterpret_cast<const Row5*>(src + y0);
-#pragma unroll
-                    for (int j = 0; j < FOV; ++j) dst[j] = t.v[j];
-                } else {
-                    for (int j = 0; j < FOV; ++j)
-                        if (y0 + j >= 0 && y0 + j < G) dst[j] = src[y0 + j];
+        // whole maps: envs that were reset (zeros, nothing loaded) or whose clock reached VISIT_RENORM (true values)
+        {
+            const int nd = ndense, per = TILES * VT;
+            for (int j = tid; j < nd * per; j += LMAZE_BLOCK) {
+                const int d = j / per, r = j - d * per;
+                const int le = dlist[d], fl = flags[le];
+                const int tile = r >> 2, row = r & 3;
+                const int tx = tile / TB, ty = tile - tx * TB;
+                uint32_t* p = vis + (le * TILES + tile) * (VT * VT) + row * VT;
+                uint32_t sv[4] = {0u, 0u, 0u, 0u};
+                if (!(fl & 16)) {
+                    const uint4 t4 = *reinterpret_cast<const uint4*>(p);
+                    sv[0] = t4.x; sv[1] = t4.y; sv[2] = t4.z; sv[3] = t4.w;
                 }
+                tile_row_whole(sv, tx * VT + row, ty * VT, le, fl & 0xff);
+                *reinterpret_cast<uint4*>(p) = make_uint4(sv[0], sv[1], sv[2], sv[3]);
             }
         }
         __syncthreads();
@@ -842,7 +881,7 @@ __global__ __launch_bounds__(LMAZE_BLOCK) void foveal_kernel(const FovealArgs a)
     nb = (int)min((int64_t)EPB, a.n - blockbase);
     __syncthreads();                                                       // every wave is done with this chunk's strings and flags
     for (int i = tid; i < EPB * 12; i += LMAZE_BLOCK) obits[i] = 0u;
-    if (tid == 0) any_skip = 0;
+    if (tid == 0) { any_skip = 0; ndense = 0; }
     __syncthreads();
   }
     if (warmed == 0x7fedcba9 && a.n < 0) a.b.done[0] = 1;   // never true: keeps the warming loads alive
@@ -999,7 +1038,7 @@ static hipError_t launch_foveal_one(const FovealArgs& a, hipStream_t s) {
     const int L = VARIANT == LMAZE_VARIANT_V1 ? 1 : a.p.n_layouts;
     // obs bit string 32 B + obs_local bit string 16 B + centres 8 B + flags 4 B + reset centre 4 B per env, row masks, layout characters, visit samples
     size_t lds = (size_t)EPB * 64 + (3 * (size_t)L * a.p.grid + 2 * (size_t)a.p.grid) * 8 + (size_t)((L * cells + 15) & ~15);
-    if (VARIANT == LMAZE_VARIANT_V4 || VARIANT == LMAZE_VARIANT_V5) lds += (size_t)EPB * 2 * W25 * 4;
+    if (VARIANT == LMAZE_VARIANT_V4 || VARIANT == LMAZE_VARIANT_V5) lds += (size_t)EPB * (2 * W25 * 4 + 8);   // + clock, whole-map list
     // launch_hint bits 8-9 (plain and fused step): chunks of EPB envs per workgroup - 1 (more than 4, or 16-env chunks: slower)
     const int64_t nchunks = (a.n + EPB - 1) / EPB;
     const int m = MODE == FM_STEP ? ((a.p.launch_hint >> 8) & 3) + 1 : 1;
@@ -1120,9 +1159,33 @@ static int check_foveal(const LmazeFovealParams* p, const uint8_t* layouts, cons
     if (p->variant == LMAZE_VARIANT_V1 && (!b->fgoal_xy || !b->foveal_step_count || !b->foveal_reward || !b->foveal_done))
         return LMAZE_E_NULL;
     if (p->variant != LMAZE_VARIANT_V1 && (!b->goal_xy || !b->layout_id)) return LMAZE_E_NULL;
-    if (p->variant == LMAZE_VARIANT_V4 && !b->visit) return LMAZE_E_NULL;
-    if (((uintptr_t)b->obs & 15) || (b->visit && ((uintptr_t)b->visit & 15))) return LMAZE_E_ALIGN;
+    if ((p->variant == LMAZE_VARIANT_V4 || v56) && (!b->visit || !b->visit_clock)) return LMAZE_E_NULL;
+    if (((uintptr_t)b->obs & 15) || (b->visit && ((uintptr_t)b->visit & 63))) return LMAZE_E_ALIGN;   // a tile = one 64-byte sector
     return 0;
+}
+
+// The reference's float[N,G,G] out of / into the clock-relative tiles (include/lmaze.h): one thread per cell.
+__global__ __launch_bounds__(LMAZE_BLOCK) void visit_materialise_kernel(const uint32_t* tiles, const int32_t* clock, float* out,
+                                                                        int64_t n, int G) {
+    const int64_t i = (int64_t)blockIdx.x * LMAZE_BLOCK + threadIdx.x;
+    const int CELLS = G * G;
+    if (i >= n * CELLS) return;
+    const int64_t e = i / CELLS;
+    const int c = (int)(i - e * CELLS), x = c / G, y = c - x * G;
+    const int TB = visit_tiles(G);
+    const uint32_t b = tiles[((size_t)e * TB * TB + (x / VT) * TB + (y / VT)) * (VT * VT) + (x % VT) * VT + (y % VT)];
+    out[i] = __uint_as_float(visit_true(b, clock[e]));
+}
+
+__global__ __launch_bounds__(LMAZE_BLOCK) void visit_load_kernel(uint32_t* tiles, int32_t* clock, const float* in, int64_t n, int G) {
+    const int64_t i = (int64_t)blockIdx.x * LMAZE_BLOCK + threadIdx.x;
+    const int TB = visit_tiles(G), PER = TB * TB * VT * VT;
+    if (i >= n * PER) return;
+    const int64_t e = i / PER;
+    const int r = (int)(i - e * PER), tile = r / (VT * VT), c = r - tile * (VT * VT);
+    const int x = (tile / TB) * VT + c / VT, y = (tile % TB) * VT + c % VT;
+    tiles[i] = (x < G && y < G) ? __float_as_uint(in[(size_t)e * G * G + x * G + y]) : 0u;
+    if (r == 0) clock[e] = VISIT_BIAS;        // stored == true value in this frame
 }
 
 static FovealArgs make_foveal_args(const LmazeFovealParams* p, const uint8_t* layouts, const LmazeFovealBuffers* b, int64_t n) {
@@ -1256,6 +1319,45 @@ int lmaze_v6_safe_foveal_goal(const LmazeFovealParams* params, const uint8_t* la
     if (!grid_ok((n + LMAZE_BLOCK - 1) / LMAZE_BLOCK)) return (int)hipErrorInvalidConfiguration;
     hipLaunchKernelGGL(safe_goal_kernel, dim3((unsigned)((n + LMAZE_BLOCK - 1) / LMAZE_BLOCK)), dim3(LMAZE_BLOCK), 0,
                        (hipStream_t)stream, a, out_goal);
+    return (int)hipGetLastError();
+}
+
+int64_t lmaze_foveal_visit_bytes(int32_t grid, int64_t n) {
+    if (grid < 1 || grid > LMAZE_MAX_GRID || n < 0) return 0;
+    const int64_t tb = visit_tiles(grid);
+    return n * tb * tb * (VT * VT) * 4;
+}
+
+static int check_visit(const LmazeFovealParams* p, const LmazeFovealBuffers* b, const void* other, int64_t n) {
+    if (!p || !b || !other || !b->visit || !b->visit_clock) return LMAZE_E_NULL;
+    if (p->grid < FOV || p->grid > LMAZE_MAX_GRID) return LMAZE_E_GRID;
+    if (n < 0 || n > LMAZE_MAX_ENVS) return LMAZE_E_COUNT;
+    if (((uintptr_t)b->visit & 63) || ((uintptr_t)other & 3)) return LMAZE_E_ALIGN;
+    return 0;
+}
+
+int lmaze_foveal_materialise_visit(const LmazeFovealParams* params, const LmazeFovealBuffers* bufs, float* out, int64_t n,
+                                   void* stream) {
+    int rc = check_visit(params, bufs, out, n);
+    if (rc) return rc;
+    if (n == 0) return 0;
+    const int64_t blocks = (n * params->grid * params->grid + LMAZE_BLOCK - 1) / LMAZE_BLOCK;
+    if (!grid_ok(blocks)) return (int)hipErrorInvalidConfiguration;
+    hipLaunchKernelGGL(visit_materialise_kernel, dim3((unsigned)blocks), dim3(LMAZE_BLOCK), 0, (hipStream_t)stream,
+                       reinterpret_cast<const uint32_t*>(bufs->visit), bufs->visit_clock, out, n, params->grid);
+    return (int)hipGetLastError();
+}
+
+int lmaze_foveal_load_visit(const LmazeFovealParams* params, const LmazeFovealBuffers* bufs, const float* in, int64_t n,
+                            void* stream) {
+    int rc = check_visit(params, bufs, in, n);
+    if (rc) return rc;
+    if (n == 0) return 0;
+    const int64_t tb = visit_tiles(params->grid);
+    const int64_t blocks = (n * tb * tb * (VT * VT) + LMAZE_BLOCK - 1) / LMAZE_BLOCK;
+    if (!grid_ok(blocks)) return (int)hipErrorInvalidConfiguration;
+    hipLaunchKernelGGL(visit_load_kernel, dim3((unsigned)blocks), dim3(LMAZE_BLOCK), 0, (hipStream_t)stream,
+                       reinterpret_cast<uint32_t*>(bufs->visit), bufs->visit_clock, in, n, params->grid);
     return (int)hipGetLastError();
 }
 

@@ -99,8 +99,15 @@ class LmazeFovealVecEnv(object):
         self.last_xy = view("last_xy", 8 * N, torch.int32, (N, 2))
         self.foveal_goal = view("foveal_goal", 4 * N, torch.int32, (N,))
         self._two_level = variant in ("v5", "v6")
-        has_visit = variant in ("v4", "v5", "v6")
-        self.visit = torch.zeros((N, G, G), dtype=torch.float32, device=self.device) if has_visit else None
+        # the visit map in the library's clock-relative 4x4 tiles (include/lmaze.h "The visit map"): opaque here; the
+        # reference's float[N,G,G] is the `visit` property (lmaze_foveal_materialise_visit)
+        self._has_visit = variant in ("v4", "v5", "v6")
+        self._visit_tiles = self._visit_clock = None
+        if self._has_visit:
+            nbytes = int(_abi.lib.lmaze_foveal_visit_bytes(G, N))
+            self._visit_tiles = torch.zeros(nbytes // 4, dtype=torch.float32, device=self.device)
+            self._visit_clock = torch.zeros(N, dtype=torch.int32, device=self.device)
+            assert self._visit_tiles.data_ptr() % 64 == 0
         self.obs_local = (torch.zeros((N, 4, _abi.FOVEA, _abi.FOVEA), dtype=torch.float32, device=self.device)
                           if self._two_level else None)
         self._expanded_local = None
@@ -116,9 +123,10 @@ class LmazeFovealVecEnv(object):
             self.ball_xy.data_ptr(), self.goal_xy.data_ptr(), self.fgoal_xy.data_ptr(), self.layout_id.data_ptr(),
             self.step_count.data_ptr(), self.foveal_step_count.data_ptr(), self.reward.data_ptr(),
             self.foveal_reward.data_ptr(), self._done_u8.data_ptr(), self._fdone_u8.data_ptr(),
-            self.visit.data_ptr() if self.visit is not None else None, self.obs.data_ptr(),
+            self._visit_tiles.data_ptr() if self._has_visit else None, self.obs.data_ptr(),
             self.ball1_xy.data_ptr(), self.fovea_xy.data_ptr(), self.last_xy.data_ptr(), self.foveal_goal.data_ptr(),
-            self.obs_local.data_ptr() if self.obs_local is not None else None)
+            self.obs_local.data_ptr() if self.obs_local is not None else None,
+            self._visit_clock.data_ptr() if self._has_visit else None)
         self._pb = C.byref(self.bufs)
         self._p_layouts = self.layouts.data_ptr()
         if variant == "v1":
@@ -154,6 +162,39 @@ class LmazeFovealVecEnv(object):
         if m.numel() != self.num_envs:
             raise ValueError("mask must have %d entries" % self.num_envs)
         return m, m.data_ptr()
+
+    # ------------------------------------------------------------------ the visit map (v4, v5, v6)
+    @property
+    def visit(self):
+        """The reference's state[2]: float32[N,G,G] true values, materialised from the clock-relative tiles (a NEW
+        tensor on every access; off the step path).  None for v1 / v2."""
+        if not self._has_visit:
+            return None
+        out = torch.empty((self.num_envs, self.grid, self.grid), dtype=torch.float32, device=self.device)
+        with self._guard():
+            rc = _abi.lib.lmaze_foveal_materialise_visit(self._pp, self._pb, out.data_ptr(), self.num_envs, self._stream())
+        _abi.check("lmaze_foveal_materialise_visit", rc)
+        return out
+
+    def load_visit(self, values):
+        """Take float32[N,G,G] true values (e.g. the reference's own state[2]) as the visit map."""
+        t = values if isinstance(values, torch.Tensor) else torch.as_tensor(np.asarray(values, dtype=np.float32))
+        t = t.to(device=self.device, dtype=torch.float32).reshape(self.num_envs, self.grid, self.grid).contiguous()
+        with self._guard():
+            rc = _abi.lib.lmaze_foveal_load_visit(self._pp, self._pb, t.data_ptr(), self.num_envs, self._stream())
+        _abi.check("lmaze_foveal_load_visit", rc)
+
+    def snapshot(self):
+        """Everything a step reads and writes except the observations: per-env scalars, visit tiles + clocks, epoch."""
+        return (self._state.clone(), self._visit_tiles.clone() if self._has_visit else None,
+                self._visit_clock.clone() if self._has_visit else None, self._epoch)
+
+    def restore(self, snap):
+        self._state.copy_(snap[0])
+        if self._has_visit:
+            self._visit_tiles.copy_(snap[1])
+            self._visit_clock.copy_(snap[2])
+        self._epoch = snap[3]
 
     # ------------------------------------------------------------------ the path
     def begin_replay(self, n_launches):
@@ -279,8 +320,8 @@ class LmazeFovealVecEnv(object):
     def autotune(self, actions, goals=None, auto_reset=False, steps=24, candidates=None, warm=100, rounds=3,
                  placement_trials=0):
         """Pick LmazeFovealParams.launch_hint by timing real steps with HIP events on the caller's own action tensor
-        (int32[T,N] on the device, rows cycled; `goals` likewise for the v5/v6 two-level step); state and visit maps
-        are snapshotted and restored, so results are unaffected.  The best (envs per workgroup, workgroups per CU)
+        (int32[T,N] on the device, rows cycled; `goals` likewise for the v5/v6 two-level step); state, visit maps and
+        the observations are snapshotted and restored, so results are unaffected.  The best (envs per workgroup, workgroups per CU)
         pair moves from device to device -- v2 at 1M envs: uncapped 96 us on one box and 102 on the next, 6 per CU 95
         and 95, 5 per CU 99 and 90 -- exactly as for the grid kernels (LmazeVecEnv.autotune).  The median of `rounds`
         interleaved passes counts and the library default (hint 0) is kept unless another hint beats it by more than
@@ -297,7 +338,8 @@ class LmazeFovealVecEnv(object):
             raise ValueError("v5/v6: autotune() times the two-level step and needs planner goals")
         cands = list(candidates or self.CANDIDATES)
         R = int(actions.shape[0])
-        snap = (self._state.clone(), None if self.visit is None else self.visit.clone(), self._epoch)
+        snap = self.snapshot()
+        obs_snap = (self.obs.clone(), None if self.obs_local is None else self.obs_local.clone())
         k = [0]
 
         def run(n):
@@ -342,10 +384,12 @@ class LmazeFovealVecEnv(object):
                     e1.synchronize()
                     ms = e0.elapsed_time(e1) / steps
                     timings.setdefault(h, []).append(ms)
-            self._state.copy_(snap[0])
-            if snap[1] is not None:
-                self.visit.copy_(snap[1])
-            self._epoch = snap[2]
+            self.restore(snap)
+            # the observations too: the tuning steps rendered into them, and with placement trials
+            # self.obs may be another allocation by now -- the caller must see the frame of the restored state
+            self.obs.copy_(obs_snap[0])
+            if obs_snap[1] is not None:
+                self.obs_local.copy_(obs_snap[1])
         timings = {h: sorted(v)[len(v) // 2] for h, v in timings.items()}
         best = min(timings, key=timings.get)
         if 0 in timings and timings[best] > 0.985 * timings[0]:

@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define LMAZE_ABI_VERSION 3
+#define LMAZE_ABI_VERSION 4
 
 /* which reference class the transition rules come from */
 enum {
@@ -271,7 +271,10 @@ typedef struct LmazeFovealBuffers {
     float* foveal_reward;       /* [N]   fovealReward               v1                                  */
     uint8_t* done;              /* [N]                                                                  */
     uint8_t* foveal_done;       /* [N]   isFovealEpisodeFinished()  v1 (v1:308-324)                     */
-    float* visit;               /* [N,G,G] visit map state[2]       v4, v5, v6 (v4:116-119, v5:313-318) */
+    float* visit;               /* visit map state[2] of v4, v5, v6 (v4:116-119, v5:313-318) in the library's own
+                                   CLOCK-RELATIVE, TILED form: lmaze_foveal_visit_bytes(G, N) bytes, 64-byte
+                                   aligned, opaque to the caller -- see "The visit map" below; the reference's
+                                   float[N,G,G] comes out of lmaze_foveal_materialise_visit                     */
     float* obs;                 /* [N,C,5,5], 16-byte aligned (v5/v6: the foveal observation, C = 7)    */
     /* v5 / v6 only (v5:62-78).  For them: reward = globalReward, foveal_reward = originalReward (the
      * local stream), done = globalDone, foveal_done = localDone, fgoal_xy = f_goal_x0/y0.               */
@@ -280,7 +283,35 @@ typedef struct LmazeFovealBuffers {
     int32_t* last_xy;           /* [N,2] window centre `retStatelast` is a view of (v5:322-323,344-346) */
     int32_t* foveal_goal;       /* [N]   index 0..24 of the one-hot fovealGoal plane (v5:166-169)        */
     float* obs_local;           /* [N,4,5,5] buildLocalObservation (v5:356-380), 16-byte aligned        */
+    int32_t* visit_clock;       /* [N]   v4, v5, v6: whole-plane halvings the map has taken in its current frame  */
 } LmazeFovealBuffers;
+
+/*
+ * The visit map (v4:116-119,211-214; v5:313-318).  The reference keeps float32[G,G] per env and, on every update,
+ * halves the WHOLE plane after adding 1 to the 5x5 window: state[2] = (state[2] + window) / 2.  Only window cells
+ * are ever observable, so this library stores each cell relative to a per-env clock instead:
+ *     stored s = v * 2^(clock - 126)      v = the reference's float32 value, clock = visit_clock[i]
+ * "halve the whole plane" is clock += 1 and touches no cell; a window cell takes v' = fl32((v + 1) / 2) -- one
+ * float32 add and an exact halving, which is the reference's float64 round trip rounded once -- and is stored
+ * under the new clock.  Reading a cell back is an exponent subtraction while v stays in the normal range; below
+ * 2^-126 the reference's own sequence of round-to-nearest-even halvings is replayed on the bit pattern (at most 25
+ * steps to 0), so cells that were last seen hundreds of steps ago still come out bit-identical.  When a clock
+ * reaches 250 the env's map is rewritten once in true values (clock := 126); reset() writes zeros (clock := 0).
+ * Layout: tiles of 4x4 cells (64 bytes, one memory sector), ceil(G/4)^2 tiles per env, row-major tiles, row-major
+ * cells inside a tile; a 5x5 window is always exactly 2x2 tiles.  A step reads and writes 256 bytes of an env's
+ * map instead of streaming all 4*G*G bytes twice.
+ */
+int64_t lmaze_foveal_visit_bytes(int32_t grid, int64_t n);
+
+/* out float[N,G,G] = the reference's state[2] of every env (true values, row-major), from the clock-relative
+ * tiles.  Off the step path (tests, LmazeEnv_v4.state, checkpoints). */
+int lmaze_foveal_materialise_visit(const LmazeFovealParams* params, const LmazeFovealBuffers* bufs, float* out,
+                                   int64_t n, void* stream);
+
+/* The inverse: take float[N,G,G] true values (e.g. the reference's own state[2]) into the tiled form;
+ * visit_clock[i] := 126, the frame in which stored == true value. */
+int lmaze_foveal_load_visit(const LmazeFovealParams* params, const LmazeFovealBuffers* bufs, const float* in,
+                            int64_t n, void* stream);
 
 /*
  * One step() of N foveal envs (v1:114-200 | v2:127-225 | v4:167-272).
@@ -308,7 +339,7 @@ int lmaze_foveal_step_autoreset(const LmazeFovealParams* params, const uint8_t* 
 
 /*
  * reset() of the envs with mask[i] != 0 (NULL = all): step_count = 0, rewards = -0.0, done
- * flags cleared, v4 visit map re-initialised ((0 + window)/2, v4:116-119), and the reset
+ * flags cleared, visit map zeroed and visit_clock = 0 (v4: then (0 + window)/2, v4:116-119), and the reset
  * observation written (v1: global view v1:204-238; v2/v4: [window, zero action plane, window],
  * v2:109-110).  place != 0 also draws the placement on the device with Philox4x32-10 keyed by
  * (seed, env_base + i, epoch): v1 ball = the 'S' cell (v1:82-84); v2 goal, ball on the CURRENT

@@ -303,8 +303,9 @@ def foveal_actions(seed, T):
     return np.random.RandomState(seed).randint(0, 25, T).astype(np.int32)
 
 
-def rollout_v24(variant, actions, seed, reset_on_done=True, random_ball=True, random_goal=True):
-    """v2 (lmaze_env_v2.py) and v4 (lmaze_env_v4.py): 25-way teleport-in-fovea action."""
+def rollout_v24(variant, actions, seed, reset_on_done=True, random_ball=True, random_goal=True, record_visit=False):
+    """v2 (lmaze_env_v2.py) and v4 (lmaze_env_v4.py): 25-way teleport-in-fovea action.  record_visit (v4): the whole
+    visit map state[2] after every step, not only the two windows the observation shows."""
     five_layouts()
     import contextlib
     import io
@@ -322,6 +323,8 @@ def rollout_v24(variant, actions, seed, reset_on_done=True, random_ball=True, ra
                reward=np.zeros(T, np.float64), done=np.zeros(T, np.uint8),
                ball=np.zeros((T, 2), np.int32), step_count=np.zeros(T, np.int32),
                planes=np.zeros((T, C, 5, 5), np.float32), obs_hash=np.zeros(T, np.uint64))
+    if record_visit:
+        rec["visit"] = np.zeros((T, 18, 18), np.float32)
     reset_planes, reset_hash = [], []
     need_reset = True
     first = None
@@ -345,11 +348,29 @@ def rollout_v24(variant, actions, seed, reset_on_done=True, random_ball=True, ra
         rec["step_count"][t] = env.stepCount
         rec["planes"][t] = unexpand(o, E)
         rec["obs_hash"][t] = obs_hash(o)
+        if record_visit:
+            rec["visit"][t] = env.state[2]
         if d and reset_on_done:
             need_reset = True
     rec["reset_planes"] = np.stack(reset_planes)
     rec["reset_hash"] = np.array(reset_hash, np.uint64)
     return rec
+
+
+def deep_decay_actions():
+    """A scripted v4 walk WITHOUT resets that leaves one corner of the map alone for 112 ... 170 steps and then returns
+    to it: the reference halves the whole float32 plane every step (lmaze_env_v4.py:211-214), so the cells there decay
+    through the normal range (exact), the subnormal range (rounded to nearest-even on EVERY step, below 2^-126) and to
+    zero (below 2^-149) before they are shown again.  Action 5*i+j teleports by (i-2, j-2), clamped to [2, 15]."""
+    rs = np.random.RandomState(91)
+    acts = []
+    for stay in (112, 125, 131, 136, 142, 150, 170):
+        acts += [24] * 8                                   # to the (15, 15) corner
+        acts += list(rs.choice([12, 13, 11, 17, 7, 18, 6], 6))   # a few steps there: multi-bit mantissas
+        acts += [0] * 8                                    # to the (2, 2) corner
+        acts += list(rs.choice([12, 13, 11, 17, 7, 12, 12], stay))
+    acts += [24] * 8 + [12] * 4
+    return np.array(acts, np.int32)
 
 
 def rollout_v1(actions, fgoals, seed, reset_on_done=True):
@@ -424,6 +445,7 @@ def gen_v4():
     save("v4_seed0", rollout_v24("v4", foveal_actions(51, 400), seed=0))
     save("v4_seed1", rollout_v24("v4", foveal_actions(52, 300), seed=1))
     save("v4_noreset_seed2", rollout_v24("v4", foveal_actions(53, 150), seed=2, reset_on_done=False))
+    save("v4_deepdecay_seed9", rollout_v24("v4", deep_decay_actions(), seed=9, reset_on_done=False, record_visit=True))
 
 
 def gen_v1():

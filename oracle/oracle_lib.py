@@ -147,7 +147,10 @@ class FovealBuffers(C.Structure):
     _fields_ = [(n, C.c_void_p) for n in ("ball_xy", "goal_xy", "fgoal_xy", "layout_id", "step_count",
                                           "foveal_step_count", "reward", "foveal_reward", "done", "foveal_done",
                                           "visit", "obs", "ball1_xy", "fovea_xy", "last_xy", "foveal_goal",
-                                          "obs_local")]
+                                          "obs_local", "visit_clock")]
+# `visit` here is the REFERENCE's dense float32[N,G,G] plane, halved whole on every update (lmaze_env_v4.py:211-214);
+# the product's clock-relative tiles (include/lmaze.h "The visit map") are compared with it through
+# lmaze_foveal_materialise_visit.  visit_clock belongs to that representation: the oracle never reads it (NULL).
 
 
 def foveal_params(variant, grid, n_layouts):
@@ -183,7 +186,8 @@ class FovealState(object):
         self.n = n
 
     def struct(self):
-        return FovealBuffers(*[getattr(self, f[0]).ctypes.data for f in FovealBuffers._fields_])
+        return FovealBuffers(*[getattr(self, f[0]).ctypes.data if f[0] != "visit_clock" else None
+                               for f in FovealBuffers._fields_])
 
 
 def foveal_step(p, layouts, action, st):

@@ -40,7 +40,7 @@ def test_header_cites_reference_lines():
 
 
 def test_abi_version_and_errors(abi):
-    assert abi.lib.lmaze_abi_version() == abi.ABI_VERSION == 3
+    assert abi.lib.lmaze_abi_version() == abi.ABI_VERSION == 4
     assert abi.strerror(0) == "ok"
     p = abi.make_params(abi.VARIANT_V0, 12, abi.LAYOUT_SHARED, 100, -1.0, -0.01, 100.0)
     # NULL pointers / bad sizes are rejected before anything is launched

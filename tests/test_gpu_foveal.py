@@ -44,6 +44,9 @@ def _replay_v24(g, variant):
         assert tuple(h["ball_xy"][0]) == tuple(g["ball"][t]), t
         assert (_bits(_np(obs)[0]) == _bits(g["planes"][t])).all(), t
         assert obs_hash(_np(env.expanded())[0]) == g["obs_hash"][t], t
+        if "visit" in g and (t % 7 == 0 or t > len(g["actions"]) - 40):
+            # v4_deepdecay: the reference's WHOLE plane out of the clock-relative tiles, cells below 2^-126 included
+            assert (_bits(_np(env.visit)[0]) == _bits(g["visit"][t])).all(), t
 
 
 @pytest.mark.parametrize("name", golden_files("v2_"))
@@ -557,13 +560,13 @@ def test_v5_hier_step_captured_replay_draws_fresh_placements():
     side = torch.cuda.Stream()
     side.wait_stream(torch.cuda.current_stream())
     graph = torch.cuda.CUDAGraph()
-    snap = (cap._state.clone(), cap.visit.clone())
+    snap = cap.snapshot()
     with torch.cuda.stream(side):
         with torch.cuda.graph(graph, stream=side):
             for t in range(T):
                 cap.hier_step_raw(acts[t].data_ptr(), goals[t].data_ptr(), epoch_slot=t)
     torch.cuda.current_stream().wait_stream(side)
-    cap._state.copy_(snap[0]); cap.visit.copy_(snap[1])      # capture does not run; make sure nothing moved
+    cap.restore(snap)      # capture does not run; make sure nothing moved
     for rep in range(2):
         cap.begin_replay(T)
         graph.replay()

@@ -101,6 +101,8 @@ def _replay_v24(g, variant):
         assert tuple(st.ball_xy[0]) == tuple(g["ball"][t]), t
         assert (st.obs[0].view(np.uint32) == g["planes"][t].view(np.uint32)).all(), t
         assert obs_hash(O.expand_planes(st.obs, E)[0]) == g["obs_hash"][t], t
+        if "visit" in g:        # v4_deepdecay: the whole plane, incl. cells decayed below 2^-126 (subnormal, rounded every step)
+            assert (st.visit[0].view(np.uint32) == g["visit"][t].view(np.uint32)).all(), t
     assert n_reset == len(g["reset_hash"])
 
 
