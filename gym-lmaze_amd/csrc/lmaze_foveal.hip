@@ -21,7 +21,7 @@
 // counts): 1 no set-up, 2 plain instead of non-temporal observation stores, 4 no observation stores, 8 no phase 1,
 // 16 stores as interleaved 4-KiB pieces, 32 no visit-map phase, 64 / 128 non-temporal visit-map stores / loads.
 #ifdef LMAZE_EXPERIMENT
-#define LMAZE_XP(args, mask) ((((args).p.launch_hint >> 16) & (mask)) != 0)
+#define LMAZE_XP(args, mask) ((((args).p.launch_hint >> 16) & (mask)) != 0)   // round 3: 256 no per-cell work on gathered tiles, 512 no "previous" window tiles
 #else
 #define LMAZE_XP(args, mask) false
 #endif
@@ -159,6 +159,14 @@ __device__ __forceinline__ void put_bits(uint32_t* bits, int off, uint32_t m) {
     if (sh > 32 - W25) atomicOr(&bits[w + 1], m >> (32 - sh));
 }
 
+// 16 bytes per lane from global memory straight into LDS (global_load_lds_dwordx4, gfx950): no register destination.
+// `lds_wave_base` is WAVE-UNIFORM: lane l's bytes land at lds_wave_base + 16 l whatever the exec mask.
+__device__ __forceinline__ void lds_dma16(const uint32_t* src, uint32_t* lds_wave_base) {
+    typedef __attribute__((address_space(1))) void gvoid;
+    typedef __attribute__((address_space(3))) void lvoid;
+    __builtin_amdgcn_global_load_lds((gvoid*)src, (lvoid*)lds_wave_base, 16, 0, 0);
+}
+
 // four consecutive floats (0.0f / 1.0f) from nibble q of a bit string
 __device__ __forceinline__ void nibble_floats(const uint32_t* bits, int q, float (&v)[4]) {
     const uint32_t nib = bits[q >> 3] >> ((q & 7) << 2);
@@ -170,6 +178,14 @@ __device__ __forceinline__ void nibble_floats(const uint32_t* bits, int q, float
 // property test of the CPU suite); here only the tile geometry.
 constexpr int VISIT_BIAS = LMAZE_VISIT_BIAS, VISIT_RENORM = LMAZE_VISIT_RENORM;
 constexpr int VT = 4;                // tile side; a tile is 16 floats = 64 bytes
+// Behind an env batch's tiles the visit buffer holds one record of VPC words per env: the true values of the 5x5 window
+// the observation shows as "previous" (retStatelast: v4:239,259, v5:322-346), word 25 = a tag naming the centre they
+// belong to.  v5/v6 show that window unchanged for up to ten steps and v4 shows last step's current window, so it is
+// kept as 112 contiguous bytes instead of being gathered from up to four more tiles every step.
+constexpr int VPC = 28;
+// Which centre the record belongs to rides in the upper bits of the env's visit_clock word (bits 0-7 the clock, bit 8
+// "record valid", bits 9-15 / 16-22 the centre): one coalesced load in phase 1 tells whether the record serves this call.
+__host__ __device__ __forceinline__ int visit_tag(int x, int y) { return 0x100 | ((x & 0x7f) << 9) | ((y & 0x7f) << 16); }
 
 __host__ __device__ __forceinline__ int visit_tiles(int G) { return (G + VT - 1) / VT; }
 __device__ __forceinline__ uint32_t visit_true(uint32_t bits, int E) { return lmaze_visit_true(bits, E); }
@@ -179,8 +195,16 @@ __device__ __forceinline__ uint32_t visit_add(uint32_t bits, int E) { return lma
 // the visit-map stream divides by G for every cell, which is only cheap with a constant
 // AR = fused auto-reset compiled in (a separate instantiation: the extra state it threads through the
 // visit-map stream costs the plain step 20 % when it is only a run-time flag)
+#ifndef LMAZE_WIN_SUB
+#define LMAZE_WIN_SUB 64    // envs whose window rows one pass of phase 2 holds in registers
+#endif
+#ifdef LMAZE_FOVEAL_WAVES   // experiment builds only (tools/_exp): force a register budget
+#define LMAZE_FOVEAL_ATTR __attribute__((amdgpu_waves_per_eu(LMAZE_FOVEAL_WAVES)))
+#else
+#define LMAZE_FOVEAL_ATTR
+#endif
 template <int VARIANT, int MODE, int EPB, int GT, bool AR>
-__global__ __launch_bounds__(LMAZE_BLOCK) void foveal_kernel(const FovealArgs a) {
+__global__ __launch_bounds__(LMAZE_BLOCK) LMAZE_FOVEAL_ATTR void foveal_kernel(const FovealArgs a) {
     constexpr bool V1 = VARIANT == LMAZE_VARIANT_V1, V5 = VARIANT == LMAZE_VARIANT_V5;
     constexpr bool V4 = VARIANT == LMAZE_VARIANT_V4 || V5;   // "has a visit map"
     constexpr int C = V1 ? 4 : (V4 ? 7 : 5);
@@ -219,6 +243,7 @@ __global__ __launch_bounds__(LMAZE_BLOCK) void foveal_kernel(const FovealArgs a)
     int nb = (int)min((int64_t)EPB, a.n - blockbase);
     if (tid == 0) { any_skip = 0; ndense = 0; }
     for (int i = tid; i < EPB * 12; i += LMAZE_BLOCK) obits[i] = 0u;       // obits and lbits
+    if (V4) for (int i = tid; i < EPB * 2 * W25; i += LMAZE_BLOCK) vwin[i] = 0.0f;   // window cells outside the array read 0
     // the reset epoch, read in front of every store (one uniform scalar load; lmaze_step.hip step_shared_kernel)
     const uint64_t epoch = launch_epoch(a.epoch, a.epoch_in);
     if (MODE == FM_STEP && AR) pass_epoch_on(a.epoch_in, a.epoch_out);
@@ -325,9 +350,11 @@ __global__ __launch_bounds__(LMAZE_BLOCK) void foveal_kernel(const FovealArgs a)
         r.skip = 0; r.flat = -1; r.action = -1; r.lid = 0; r.gx = r.gy = -9;
         r.b0x = r.b0y = r.b1x = r.b1y = r.f1x = r.f1y = 0; r.upd = 0; r.pad = 0;
         bool fresh = false, nostep = false;   // fused reset: new episode this call / its step was refused
+        bool last_is_cur = true;              // v5/v6: the window shown as "previous" from now on is this call's current one
         int rx = 0, ry = 0;                   // ball the fused reset placed
         int bx = a.b.ball_xy[2 * e], by = a.b.ball_xy[2 * e + 1];
-        const int vclock = (V4 && !(V5 && MODE == FM_PLANNER)) ? a.b.visit_clock[e] : 0;
+        const int vword = (V4 && !(V5 && MODE == FM_PLANNER)) ? a.b.visit_clock[e] : 0;
+        const int vclock = vword & 0xff;
         r.px = (int16_t)bx; r.py = (int16_t)by;
         if (MODE != FM_STEP && a.mask && !a.mask[e]) r.skip = 1;
         if (V1) {
@@ -468,6 +495,7 @@ __global__ __launch_bounds__(LMAZE_BLOCK) void foveal_kernel(const FovealArgs a)
                 r.px = (int16_t)lx; r.py = (int16_t)ly;                // window the foveal obs shows as "previous"
                 r.upd = ld ? 1 : 0;                                    // v5:313-318
                 if (ld) { lx = f0x; ly = f0y; }                        // v5:344-346 (after the render)
+                last_is_cur = lx == f0x && ly == f0y;
                 a.b.ball_xy[2 * e] = bx; a.b.ball_xy[2 * e + 1] = by;
                 a.b.ball1_xy[2 * e] = b1x; a.b.ball1_xy[2 * e + 1] = b1y;
                 a.b.fovea_xy[4 * e] = f0x; a.b.fovea_xy[4 * e + 1] = f0y;
@@ -643,9 +671,18 @@ __global__ __launch_bounds__(LMAZE_BLOCK) void foveal_kernel(const FovealArgs a)
             const bool renorm = !zero && vclock >= VISIT_RENORM;
             const bool pre = !V5 && MODE == FM_STEP && AR && fresh;
             const bool add = !(V5 && MODE == FM_RESET) && !nostep && !(V5 && MODE == FM_STEP && !r.upd);
-            fl |= (zero ? 16 : 0) | (renorm ? 32 : 0) | (pre ? 64 : 0) | (add ? 128 : 0);
-            const int c1 = (zero ? 0 : (renorm ? VISIT_BIAS : vclock)) + (pre ? 1 : 0) + (add ? 1 : 0);
-            if (c1 != vclock) a.b.visit_clock[e] = c1;
+            // the "previous window" record behind the tiles: it must hold the window the NEXT call shows as previous, in
+            // true values -- this call's current window (cw0: v4 always; v5/v6 when retStatelast moved, v5:322-346), or
+            // the previous one as this call left it (cw1: the map or the episode changed under it)
+            const bool cw0 = V5 && (MODE == FM_RESET || last_is_cur);
+            const bool cw1 = V5 && !cw0 && (fresh || add);
+            // v5/v6: does the env's record hold the window this call shows as "previous"?  (a freshly loaded state does not)
+            const bool hit = V5 && !zero && (vword >> 8) == (visit_tag(r.px, r.py) >> 8);
+            fl |= (zero ? 16 : 0) | (renorm ? 32 : 0) | (pre ? 64 : 0) | (add ? 128 : 0) | (cw0 ? 256 : 0) | (cw1 ? 512 : 0) | (hit ? 1024 : 0);
+            int c1 = (zero ? 0 : (renorm ? VISIT_BIAS : vclock)) + (pre ? 1 : 0) + (add ? 1 : 0);
+            // the record's tag: the centre it will hold after this call (cw0 / cw1), else as it was
+            if (V5) c1 |= cw0 ? visit_tag(r.cx, r.cy) : (cw1 ? visit_tag(r.px, r.py) : (vword & ~0xff));
+            if (c1 != vword) a.b.visit_clock[e] = c1;
             if (zero || renorm) dlist[atomicAdd(&ndense, 1)] = le;
         }
         if (V4) clk[le] = vclock;
@@ -658,43 +695,24 @@ __global__ __launch_bounds__(LMAZE_BLOCK) void foveal_kernel(const FovealArgs a)
 
     // ---------------- phase 2 (v4-v6): the visit maps, v4:116-119 / v4:211-214 / v5:313-318 ----------------
     // Clock-relative tiles (include/lmaze.h "The visit map"): the whole-plane halving already happened in phase 1 (the
-    // env's clock moved); what is left is the 5x5 window.  Every env gathers the 2 x 2 tiles under its current window
-    // and the 2 x 2 under the "previous" one (those it does not share with the first), one lane per tile row (16 B),
-    // every load of the workgroup in flight before the first is used; cells inside the current window take
-    // (v + 1) / 2 when the map updates this call, the tiles go back whole (64-byte sectors, no partial writes), and the
-    // two windows' TRUE values -- the "previous" one sampled live from the updated map, Appendix B-7 -- are left in
-    // LDS for phase 3.  The few envs whose whole map is rewritten (reset: zeros; clock at VISIT_RENORM: true values)
-    // are streamed tile by tile after that.
+    // env's clock moved); what is left is the 5x5 window, ONE CELL PER LANE, registers only:
+    //   pass 1  lane (env, window 0: current / 1: "previous", cell 0..24) loads its cell -- from the env's tiles (the
+    //           current window always covers exactly 2 x 2 of them: 3 memory lines on average) or, v5/v6, from the
+    //           env's "previous window" record (112 contiguous bytes) when that window lies elsewhere; every load of 64
+    //           envs is in flight before the first is used;
+    //   pass 2  (after a barrier: no cell is stored before every lane that shows it has loaded it) a cell inside the
+    //           current window takes (v + 1) / 2 when the map updates this call and goes back re-encoded under the new
+    //           clock -- a 4-byte store into a line the load has just brought into L2 --, and the TRUE values both
+    //           windows show (the previous one sampled live from the updated map, Appendix B-7) are left in vwin.
+    // The few envs whose whole map is rewritten (reset: zeros; clock at VISIT_RENORM: true values) are streamed tile by
+    // tile.  (Tried and dropped this round: whole tiles through registers, 16 B per lane -- the per-row bookkeeping made
+    // the phase issue-bound, 130 of 440 us --, and whole tiles staged in LDS by LDS-DMA -- 640 B of LDS per env left 3
+    // workgroups per CU.)
     if (V4 && !(V5 && MODE == FM_PLANNER) && !LMAZE_XP(a, 32)) {
         const int TB = visit_tiles(G), TILES = TB * TB;
         uint32_t* vis = reinterpret_cast<uint32_t*>(a.b.visit) + (size_t)blockbase * TILES * (VT * VT);
-        // One tile row of a GATHERED tile: cells (x, y0 .. y0 + 3) of env le, stored values in s[].  A cell inside the
-        // current window takes (v + 1) / 2 when the map updates this call (`add`); the true values of the cells the two
-        // windows show -- under the clock the call ends with -- go to vwin.  One decode per cell, none for cells outside
-        // both windows.
-        auto tile_row = [&](uint32_t (&s)[4], int x, int y0, int le, bool add) {
-            const int E0 = clk[le];
-            const int dx = x - cen[le * 4] + 2, ex = x - cen[le * 4 + 2] + 2;
-            const int dy0 = y0 - cen[le * 4 + 1] + 2, ey0 = y0 - cen[le * 4 + 3] + 2;
-            const bool rowc = x < G && (unsigned)dx <= 4u, rowp = x < G && (unsigned)ex <= 4u;
-            if (!rowc && !rowp) return;
-#pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                const bool in = rowc && (unsigned)(dy0 + k) <= 4u && y0 + k < G;
-                const bool inp = rowp && (unsigned)(ey0 + k) <= 4u && y0 + k < G;
-                if (!in && !inp) continue;
-                const bool upd = in && add;
-                uint32_t t = visit_true(s[k], upd ? E0 : E0 + (add ? 1 : 0));
-                if (upd) {
-                    const float w = (__uint_as_float(t) + 1.0f) * 0.5f;       // v4:214; see visit_add
-                    t = __float_as_uint(w);
-                    s[k] = lmaze_visit_store(w, E0 + 1);
-                }
-                if (in) vwin[le * 2 * W25 + dx * FOV + dy0 + k] = __uint_as_float(t);
-                if (inp) vwin[le * 2 * W25 + W25 + ex * FOV + ey0 + k] = __uint_as_float(t);
-            }
-        };
-        // The same for an env whose WHOLE map is rewritten this call: zeros (reset) or true values (clock at
+        uint32_t* rec = reinterpret_cast<uint32_t*>(a.b.visit) + (size_t)a.n * TILES * (VT * VT) + (size_t)blockbase * VPC;
+        // One tile row of an env whose WHOLE map is rewritten this call: zeros (reset) or true values (clock at
         // VISIT_RENORM) first, then the fused reset's own window at the placed ball (`pre`, v4:116-119), then `add`.
         auto tile_row_whole = [&](uint32_t (&s)[4], int x, int y0, int le, int fl) {
             const int E0 = clk[le];
@@ -727,53 +745,7 @@ __global__ __launch_bounds__(LMAZE_BLOCK) void foveal_kernel(const FovealArgs a)
                     vwin[le * 2 * W25 + W25 + ex * FOV + ey] = __uint_as_float(visit_true(b, E));
             }
         };
-        // window cells outside the array read 0 (the padded layouts never get there)
-        for (int i = tid; i < nb * 2 * W25; i += LMAZE_BLOCK) vwin[i] = 0.0f;
-        __syncthreads();
-        {
-            // item = (env, set 0: current window / 1: "previous" window, tile 0..3 of the 2 x 2, row 0..3 of the tile)
-            constexpr int UNR = 4, IPE = 2 * 4 * VT;
-            const int items = nb * IPE;
-            for (int i0 = tid; i0 < items; i0 += UNR * LMAZE_BLOCK) {
-                uint4 v[UNR];
-                int off[UNR], meta[UNR];     // meta: env | x << 8 | y << 15 | set << 22 | flags << 24
-#pragma unroll
-                for (int u = 0; u < UNR; ++u) {
-                    const int i = i0 + u * LMAZE_BLOCK;
-                    const int le = i / IPE, r = i - le * IPE;
-                    const int set = r >> 4, t = (r >> 2) & 3, row = r & 3;
-                    off[u] = -1;
-                    meta[u] = 0;
-                    if (i >= items) continue;
-                    const int fl = flags[le];
-                    if (fl & (1 | 16 | 32)) continue;                       // untouched, or rewritten whole below
-                    const int ta = (cen[le * 4] - 2) >> 2, tb = (cen[le * 4 + 1] - 2) >> 2;   // first tile row / column of the current window
-                    int tx, ty;
-                    if (set == 0) {
-                        tx = ta + (t >> 1); ty = tb + (t & 1);
-                    } else {
-                        tx = ((cen[le * 4 + 2] - 2) >> 2) + (t >> 1); ty = ((cen[le * 4 + 3] - 2) >> 2) + (t & 1);
-                        if ((unsigned)(tx - ta) <= 1u && (unsigned)(ty - tb) <= 1u) continue;   // the current window's item has it
-                    }
-                    if ((unsigned)tx >= (unsigned)TB || (unsigned)ty >= (unsigned)TB) continue;
-                    off[u] = (le * TILES + tx * TB + ty) * (VT * VT) + row * VT;
-                    meta[u] = le | ((tx * VT + row) << 8) | ((ty * VT) << 15) | (set << 22) | ((fl & 0xff) << 24);
-                }
-#pragma unroll
-                for (int u = 0; u < UNR; ++u)
-                    if (off[u] >= 0) v[u] = *reinterpret_cast<const uint4*>(vis + off[u]);
-#pragma unroll
-                for (int u = 0; u < UNR; ++u) {
-                    if (off[u] < 0) continue;
-                    uint32_t sv[4] = {v[u].x, v[u].y, v[u].z, v[u].w};
-                    const int fl = (meta[u] >> 24) & 0xff;
-                    tile_row(sv, (meta[u] >> 8) & 127, (meta[u] >> 15) & 127, meta[u] & 255, (fl & 128) != 0);
-                    if ((fl & 128) && !((meta[u] >> 22) & 1))             // the map updated: the current window's tiles go back
-                        *reinterpret_cast<uint4*>(vis + off[u]) = make_uint4(sv[0], sv[1], sv[2], sv[3]);
-                }
-            }
-        }
-        // whole maps: envs that were reset (zeros, nothing loaded) or whose clock reached VISIT_RENORM (true values)
+        // ---- whole maps first: envs that were reset (zeros, nothing loaded) or whose clock reached VISIT_RENORM
         {
             const int nd = ndense, per = TILES * VT;
             for (int j = tid; j < nd * per; j += LMAZE_BLOCK) {
@@ -791,7 +763,153 @@ __global__ __launch_bounds__(LMAZE_BLOCK) void foveal_kernel(const FovealArgs a)
                 *reinterpret_cast<uint4*>(p) = make_uint4(sv[0], sv[1], sv[2], sv[3]);
             }
         }
+        // ---- the windows: ONE LANE PER WINDOW ROW.  Item = (env, window 0: current / 1: "previous", row 0..4): the row's
+        // five cells lie in two horizontally adjacent tiles, on one tile row each -- two 16-byte loads, eight words, the
+        // five wanted ones start at word y0 & 3 --, or, v5/v6, in the env's "previous window" record (20 contiguous
+        // bytes) when that window lies elsewhere.  Every load of the chunk is in flight before the first is used, and
+        // nothing is stored before every lane has its loads (the barrier): a cell both windows show is loaded by two
+        // lanes and each works out the same new value for it.  Cells of the current window take (v + 1) / 2 when the map
+        // updates this call and the two 16-byte pieces go back re-encoded under the new clock (into lines the loads have
+        // just brought into L2); the TRUE values both windows show -- the previous one sampled live from the updated
+        // map, Appendix B-7 -- are left in vwin for phase 3.
+        {
+            // SUB envs at a time (one barrier each): the loads of a pass are held in registers, 9 per row
+            constexpr int IPE = 2 * FOV, SUB = EPB < LMAZE_WIN_SUB ? EPB : LMAZE_WIN_SUB, NIT = (SUB * IPE + LMAZE_BLOCK - 1) / LMAZE_BLOCK;
+          for (int sb = 0; sb < nb; sb += SUB) {
+            const int items = LMAZE_XP(a, 256) ? 0 : min(SUB, nb - sb) * IPE;
+            uint4 va[NIT], vb[NIT];
+            int meta[NIT];    // -1 nothing; else global word offset of piece A (tiles) or of the row (record) | 1 << 28 record | 1 << 29 piece A outside | 1 << 30 piece B outside
+#pragma unroll
+            for (int u = 0; u < NIT; ++u) {
+                const int i = tid + u * LMAZE_BLOCK;
+                meta[u] = -1;
+                va[u] = make_uint4(0u, 0u, 0u, 0u);
+                vb[u] = make_uint4(0u, 0u, 0u, 0u);
+                if (i >= items) continue;
+                const int le = sb + i / IPE, r = i % IPE;
+                const int w = r >= FOV ? 1 : 0, row = r - w * FOV;
+                const int fl = flags[le];
+                if (fl & (1 | 16 | 32)) continue;                           // untouched, or rewritten whole above
+                const int cx = cen[le * 4], cy = cen[le * 4 + 1];
+                const int wx = cen[le * 4 + 2 * w], wy = cen[le * 4 + 2 * w + 1];
+                const int x = wx - 2 + row, y0 = wy - 2;
+                if ((unsigned)x >= (unsigned)G) continue;                   // outside the array: stays 0
+                // v5/v6: the record serves the previous window unless this call's update reaches into this row
+                const bool touched = (fl & 128) && (unsigned)(x - cx + 2) <= 4u && (unsigned)(wy - cy + 4) <= 8u;
+                if (V5 && w == 1 && (fl & 1024) && !touched) {
+                    const int o = le * VPC + row * FOV;
+                    struct __attribute__((packed, aligned(4))) Q4 { uint32_t v[4]; };
+                    const Q4 q = *reinterpret_cast<const Q4*>(rec + o);
+                    va[u] = make_uint4(q.v[0], q.v[1], q.v[2], q.v[3]);
+                    vb[u].x = rec[o + 4];
+                    meta[u] = o | (1 << 28);
+                } else {
+                    const int ty0 = y0 >> 2;                                // floor: -1 when the window pokes out on the left
+                    const int o = (le * TILES + (x >> 2) * TB + ty0) * (VT * VT) + (x & 3) * VT;
+                    const bool a_out = ty0 < 0, b_out = ty0 + 1 >= TB;
+                    if (!a_out) va[u] = *reinterpret_cast<const uint4*>(vis + o);
+                    if (!b_out) vb[u] = *reinterpret_cast<const uint4*>(vis + o + VT * VT);
+                    meta[u] = (o & 0x0fffffff) | (a_out ? 1 << 29 : 0) | (b_out ? 1 << 30 : 0);
+                }
+            }
+            __syncthreads();       // every load of this chunk's envs has returned before any of their cells is stored
+#pragma unroll
+            for (int u = 0; u < NIT; ++u) {
+                if (meta[u] < 0) continue;
+                const int i = tid + u * LMAZE_BLOCK;
+                const int le = sb + i / IPE, r = i % IPE;
+                const int w = r >= FOV ? 1 : 0, row = r - w * FOV;
+                const int fl = flags[le], E0 = clk[le];
+                const bool add = fl & 128, from_rec = (meta[u] >> 28) & 1;
+                const int cx = cen[le * 4], cy = cen[le * 4 + 1];
+                const int x = cen[le * 4 + 2 * w] - 2 + row, y0 = cen[le * 4 + 2 * w + 1] - 2;
+                const int sh = from_rec ? 0 : (y0 & 3);
+                // the eight words rotated so that the row's cells are c[0..4]
+                uint32_t c[8] = {va[u].x, va[u].y, va[u].z, va[u].w, vb[u].x, vb[u].y, vb[u].z, vb[u].w};
+                if (sh & 1) {
+#pragma unroll
+                    for (int k = 0; k < 7; ++k) c[k] = c[k + 1];
+                }
+                if (sh & 2) {
+#pragma unroll
+                    for (int k = 0; k < 6; ++k) c[k] = c[k + 2];
+                }
+                const bool rowc = (unsigned)(x - cx + 2) <= 4u;
+                bool changed = false;
+                float* out = vwin + le * 2 * W25 + w * W25 + row * FOV;
+                const bool rec_out = V5 && (fl & (w == 0 ? 256 : 512));     // v5/v6: the record takes the window the NEXT call shows as previous
+                // One cell: its true value under the clock this call ends with (a record holds true values, i.e. values stored
+                // under clock VISIT_BIAS, and serves a row only when this call's update does not reach into it; a cell outside
+                // the current window only takes the whole-plane halving of this call's update, if there is one).  `slow`: decode
+                // by lmaze_visit_true (values that decayed below 2^-126) instead of the exponent subtraction.
+                auto one_cell = [&](uint32_t& cj, int j, bool slow) -> bool {
+                    const int y = y0 + j;
+                    if ((unsigned)y >= (unsigned)G) return false;           // outside the array: stays 0
+                    const bool in_cur = !from_rec && rowc && (unsigned)(y - cy + 2) <= 4u;
+                    const int E = in_cur ? E0 : (from_rec ? VISIT_BIAS : E0) + (add ? 1 : 0);
+                    const int n = E - VISIT_BIAS, f = (int)(cj >> 23);
+                    const bool fast = cj == 0u || (f >= 1 && f - n >= 1);
+                    uint32_t t = slow ? visit_true(cj, E) : (cj == 0u ? 0u : (uint32_t)((int)cj - n * (1 << 23)));
+                    if (in_cur && add) {
+                        const float nv = (__uint_as_float(t) + 1.0f) * 0.5f;    // v4:214; see lmaze_visit_add
+                        t = __float_as_uint(nv);
+                        if (fast || slow) cj = lmaze_visit_store(nv, E0 + 1);
+                        changed = true;
+                    }
+                    out[j] = __uint_as_float(t);
+                    if (rec_out) rec[le * VPC + row * FOV + j] = t;
+                    return !fast;
+                };
+                uint32_t redo = 0u;
+#pragma unroll
+                for (int j = 0; j < FOV; ++j) redo |= one_cell(c[j], j, false) ? 1u << j : 0u;
+#pragma unroll 1
+                for (; redo; redo &= redo - 1u) {                           // rare: cells below 2^-126
+                    const int j = __ffs((int)redo) - 1;
+                    uint32_t cj = j == 0 ? c[0] : (j == 1 ? c[1] : (j == 2 ? c[2] : (j == 3 ? c[3] : c[4])));
+                    one_cell(cj, j, true);
+                    c[0] = j == 0 ? cj : c[0]; c[1] = j == 1 ? cj : c[1]; c[2] = j == 2 ? cj : c[2];
+                    c[3] = j == 3 ? cj : c[3]; c[4] = j == 4 ? cj : c[4];
+                }
+                if (w == 0 && changed) {
+                    // the updated words back where they came from: word k of the row sits at c[k - sh] for k >= sh
+                    uint32_t d[8] = {va[u].x, va[u].y, va[u].z, va[u].w, vb[u].x, vb[u].y, vb[u].z, vb[u].w};
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) {
+#pragma unroll
+                        for (int j = 0; j < FOV; ++j)
+                            if (k - j >= 0 && k - j <= 3 && sh == k - j) d[k] = c[j];
+                    }
+                    const int o = meta[u] & 0x0fffffff;
+                    if (!((meta[u] >> 29) & 1)) *reinterpret_cast<uint4*>(vis + o) = make_uint4(d[0], d[1], d[2], d[3]);
+                    if (!((meta[u] >> 30) & 1)) *reinterpret_cast<uint4*>(vis + o + VT * VT) = make_uint4(d[4], d[5], d[6], d[7]);
+                }
+            }
+            if (V5) {
+                // rows of a new record that lie outside the array hold zeros
+                for (int i = tid; i < items; i += LMAZE_BLOCK) {
+                    const int le = sb + i / IPE, r = i % IPE;
+                    const int w = r >= FOV ? 1 : 0, row = r - w * FOV;
+                    const int fl = flags[le];
+                    if ((fl & (1 | 16 | 32)) || !(fl & (w == 0 ? 256 : 512))) continue;
+                    const int x = cen[le * 4 + 2 * w] - 2 + row, y0 = cen[le * 4 + 2 * w + 1] - 2;
+                    for (int j = 0; j < FOV; ++j)
+                        if ((unsigned)x >= (unsigned)G || (unsigned)(y0 + j) >= (unsigned)G) rec[le * VPC + row * FOV + j] = 0u;
+                }
+            }
+          }
+        }
         __syncthreads();
+        if (V5) {
+            // whole-map envs (reset / renormalised this call): their window values are in vwin now
+            const int nd = ndense;
+            for (int j = tid; j < nd * W25; j += LMAZE_BLOCK) {
+                const int le = dlist[j / W25], k = j % W25, fl = flags[le];
+                if (!(fl & (256 | 512))) continue;
+                const int wsel = (fl & 256) ? 0 : 1;
+                rec[le * VPC + k] = __float_as_uint(vwin[le * 2 * W25 + wsel * W25 + k]);
+            }
+        }
     }
 
     // ---------------- phase 3: render float[nb*C*25], contiguous, 16-byte stores ----------------
@@ -881,6 +999,7 @@ __global__ __launch_bounds__(LMAZE_BLOCK) void foveal_kernel(const FovealArgs a)
     nb = (int)min((int64_t)EPB, a.n - blockbase);
     __syncthreads();                                                       // every wave is done with this chunk's strings and flags
     for (int i = tid; i < EPB * 12; i += LMAZE_BLOCK) obits[i] = 0u;
+    if (V4) for (int i = tid; i < EPB * 2 * W25; i += LMAZE_BLOCK) vwin[i] = 0.0f;
     if (tid == 0) { any_skip = 0; ndense = 0; }
     __syncthreads();
   }
@@ -1032,13 +1151,32 @@ __global__ __launch_bounds__(LMAZE_BLOCK) void expand_planes_stream_kernel(const
 // ------------------------------------------------------------------------------------
 constexpr size_t kFovealStreamBytes = (size_t)192 << 20;   // observations larger than this are streamed (non-temporal stores)
 
+// LDS one workgroup may ask for on this device (160 KiB on gfx950), queried once
+static size_t lds_limit() {
+    static size_t limit = 0;
+    if (limit == 0) {
+        int dev = 0, v = 0;
+        if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&v, hipDeviceAttributeMaxSharedMemoryPerBlock, dev) == hipSuccess && v > 0)
+            limit = (size_t)v;
+        else
+            limit = 64 * 1024;
+    }
+    return limit;
+}
+
 template <int VARIANT, int MODE, int EPB>
 static hipError_t launch_foveal_one(const FovealArgs& a, hipStream_t s) {
     const int cells = a.p.grid * a.p.grid;
     const int L = VARIANT == LMAZE_VARIANT_V1 ? 1 : a.p.n_layouts;
     // obs bit string 32 B + obs_local bit string 16 B + centres 8 B + flags 4 B + reset centre 4 B per env, row masks, layout characters, visit samples
     size_t lds = (size_t)EPB * 64 + (3 * (size_t)L * a.p.grid + 2 * (size_t)a.p.grid) * 8 + (size_t)((L * cells + 15) & ~15);
-    if (VARIANT == LMAZE_VARIANT_V4 || VARIANT == LMAZE_VARIANT_V5) lds += (size_t)EPB * (2 * W25 * 4 + 8);   // + clock, whole-map list
+    if (VARIANT == LMAZE_VARIANT_V4 || VARIANT == LMAZE_VARIANT_V5)
+        lds += (size_t)EPB * (2 * W25 * 4 + 8);   // + visit samples, clock, whole-map list
+    // envs per workgroup is a performance knob (launch_hint bits 4-7): a size whose LDS does not fit the device falls
+    // back to the next smaller one instead of failing the launch (v4-v6 at 256 envs: 164 KiB)
+    if constexpr (EPB > 32) {
+        if (lds > lds_limit()) return launch_foveal_one<VARIANT, MODE, EPB / 2>(a, s);
+    }
     // launch_hint bits 8-9 (plain and fused step): chunks of EPB envs per workgroup - 1 (more than 4, or 16-env chunks: slower)
     const int64_t nchunks = (a.n + EPB - 1) / EPB;
     const int m = MODE == FM_STEP ? ((a.p.launch_hint >> 8) & 3) + 1 : 1;
@@ -1054,7 +1192,7 @@ static hipError_t launch_foveal_one(const FovealArgs& a, hipStream_t s) {
     if (MODE == FM_STEP && per_cu >= 1 && per_cu <= 8) {
         const size_t cap = 160 * 1024;
         const size_t want = ((cap / per_cu + cap / (per_cu + 1)) / 2) & ~(size_t)255;   // between the two thresholds
-        if (want > lds && want <= 64 * 1024) lds = want;
+        if (want > lds && want <= lds_limit()) lds = want;     // per_cu 1 (120 KiB) and 2 (66 KiB) included where the device allows
     }
     const dim3 grid((unsigned)blocks), block(LMAZE_BLOCK);
     if constexpr (MODE == FM_STEP) {
@@ -1174,7 +1312,7 @@ __global__ __launch_bounds__(LMAZE_BLOCK) void visit_materialise_kernel(const ui
     const int c = (int)(i - e * CELLS), x = c / G, y = c - x * G;
     const int TB = visit_tiles(G);
     const uint32_t b = tiles[((size_t)e * TB * TB + (x / VT) * TB + (y / VT)) * (VT * VT) + (x % VT) * VT + (y % VT)];
-    out[i] = __uint_as_float(visit_true(b, clock[e]));
+    out[i] = __uint_as_float(visit_true(b, clock[e] & 0xff));
 }
 
 __global__ __launch_bounds__(LMAZE_BLOCK) void visit_load_kernel(uint32_t* tiles, int32_t* clock, const float* in, int64_t n, int G) {
@@ -1185,7 +1323,7 @@ __global__ __launch_bounds__(LMAZE_BLOCK) void visit_load_kernel(uint32_t* tiles
     const int r = (int)(i - e * PER), tile = r / (VT * VT), c = r - tile * (VT * VT);
     const int x = (tile / TB) * VT + c / VT, y = (tile % TB) * VT + c % VT;
     tiles[i] = (x < G && y < G) ? __float_as_uint(in[(size_t)e * G * G + x * G + y]) : 0u;
-    if (r == 0) clock[e] = VISIT_BIAS;        // stored == true value in this frame
+    if (r == 0) clock[e] = VISIT_BIAS;        // stored == true value in this frame; record tag cleared: the next step reads the tiles
 }
 
 static FovealArgs make_foveal_args(const LmazeFovealParams* p, const uint8_t* layouts, const LmazeFovealBuffers* b, int64_t n) {
@@ -1325,7 +1463,7 @@ int lmaze_v6_safe_foveal_goal(const LmazeFovealParams* params, const uint8_t* la
 int64_t lmaze_foveal_visit_bytes(int32_t grid, int64_t n) {
     if (grid < 1 || grid > LMAZE_MAX_GRID || n < 0) return 0;
     const int64_t tb = visit_tiles(grid);
-    return n * tb * tb * (VT * VT) * 4;
+    return n * (tb * tb * (VT * VT) + VPC) * 4;      // tiles, then one "previous window" record per env
 }
 
 static int check_visit(const LmazeFovealParams* p, const LmazeFovealBuffers* b, const void* other, int64_t n) {

@@ -26,6 +26,7 @@ LMAZE_HD uint32_t lmaze_float_bits(float f) { union { uint32_t u; float f; } c; 
 // on EVERY step from there -- replayed here one step at a time (dropping one bit is either exact or a tie), at most 25
 // steps before any value is 0.  n < 0 (a clock below the frame a subnormal was stored in) doubles, always exact.
 LMAZE_HD uint32_t lmaze_visit_true_slow(uint32_t bits, int n) {
+    if (n < -300) n = -300;                   // a corrupted clock must not turn into a long loop (the result is garbage anyway)
     for (; n < 0; ++n) bits = (bits >> 23) ? bits + (1u << 23) : bits << 1;
     if (n == 0) return bits;
     const int f = (int)(bits >> 23);

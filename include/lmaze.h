@@ -283,7 +283,9 @@ typedef struct LmazeFovealBuffers {
     int32_t* last_xy;           /* [N,2] window centre `retStatelast` is a view of (v5:322-323,344-346) */
     int32_t* foveal_goal;       /* [N]   index 0..24 of the one-hot fovealGoal plane (v5:166-169)        */
     float* obs_local;           /* [N,4,5,5] buildLocalObservation (v5:356-380), 16-byte aligned        */
-    int32_t* visit_clock;       /* [N]   v4, v5, v6: whole-plane halvings the map has taken in its current frame  */
+    int32_t* visit_clock;       /* [N]   v4, v5, v6: bits 0-7 the whole-plane halvings the map has taken in its current
+                                   frame; the library keeps a tag in the upper bits (v5/v6: which window centre the
+                                   env's "previous window" record behind the tiles belongs to).  Opaque, as `visit`. */
 } LmazeFovealBuffers;
 
 /*
@@ -298,8 +300,11 @@ typedef struct LmazeFovealBuffers {
  * steps to 0), so cells that were last seen hundreds of steps ago still come out bit-identical.  When a clock
  * reaches 250 the env's map is rewritten once in true values (clock := 126); reset() writes zeros (clock := 0).
  * Layout: tiles of 4x4 cells (64 bytes, one memory sector), ceil(G/4)^2 tiles per env, row-major tiles, row-major
- * cells inside a tile; a 5x5 window is always exactly 2x2 tiles.  A step reads and writes 256 bytes of an env's
- * map instead of streaming all 4*G*G bytes twice.
+ * cells inside a tile; a 5x5 window is always exactly 2x2 tiles (3 memory lines of 128 bytes on average).  A step
+ * reads ten and writes back at most ten 16-byte tile rows of an env's map instead of streaming all 4*G*G bytes
+ * twice.  Behind the tiles of the whole batch sit N records of 28 words: the true values of the window the
+ * observation shows as "previous" (v5/v6 show it unchanged for up to ten steps: 112 contiguous bytes instead of a
+ * second gather).  lmaze_foveal_visit_bytes() covers both.
  */
 int64_t lmaze_foveal_visit_bytes(int32_t grid, int64_t n);
 

@@ -18,6 +18,9 @@ modes = {"full": 0, "no_setup": 1, "no_stores": 4, "no_phase1": 8, "stores_only"
 if os.environ.get("DECOMPOSE_VISIT"):     # v4 / v5: the visit-map stream (bit 13) as well
     modes = {"full": 0, "no_setup": 1, "no_stores": 4, "no_phase1": 8, "no_visit_stream": 32, "stores_only": 41,
              "visit_stream only": 13, "phase1 only": 37, "phase1 + visit": 5}
+if os.environ.get("DECOMPOSE_R3"):        # round 3: the gathered-tile visit phase: per-cell work off (256), "previous" window tiles off (512)
+    modes = {"full": 0, "no cell work": 256, "no prev tiles": 512, "neither": 768, "no_visit": 32, "no_stores": 4,
+             "no_stores no cell work": 260, "no_stores neither": 772}
 if os.environ.get("DECOMPOSE_NTMAP"):     # v4: non-temporal accesses for the visit-map stream
     modes = {"full": 0, "nt map stores": 64, "nt map loads": 128, "nt both": 192, "visit only": 13, "visit only nt both": 13 + 192,
              "visit only nt stores": 13 + 64}

@@ -95,6 +95,66 @@ __global__ __launch_bounds__(256) void window_kernel(float* maps, float* obs, fl
     if (acc == 123456.789f) sink[tid] = acc;
 }
 
+// t64 tiles again, but ONE CELL PER LANE: 25 dword loads per env (the window), +1, 25 dword stores back (partial-sector
+// writes into lines the loads have just brought into L2) -- against the whole-tile version above.  RECS: 25 more lanes per
+// env read a dense 112-byte record (the "previous window" record) instead of a second window.
+template <bool WRITE, bool OBS, bool RECS>
+__global__ __launch_bounds__(256) void cell_kernel(float* maps, float* recs, float* obs, float* sink, int n, uint32_t seed, int epb) {
+    const int tid = threadIdx.x;
+    const int base = blockIdx.x * epb;
+    const int nb = min(epb, n - base);
+    constexpr int IPE = RECS ? 50 : 25;
+    float acc = 0.f;
+    for (int i = tid; i < nb * IPE; i += 256) {
+        const int le = i / IPE, it = i - le * IPE;
+        const int e = base + le;
+        const uint32_t h = hash32((uint32_t)e * 2654435761u + seed);
+        const int ox = (int)(h % 14u), oy = (int)((h >> 8) % 14u);
+        if (it < 25) {
+            const int x = ox + it / 5, y = oy + it % 5;
+            float* p = maps + (size_t)e * 400 + ((x >> 2) * 5 + (y >> 2)) * 16 + (x & 3) * 4 + (y & 3);
+            const float v = *p;
+            acc += v;
+            if (WRITE) *p = v + 1.f;
+        } else {
+            acc += recs[(size_t)e * 28 + it - 25];
+        }
+    }
+    if (OBS) {
+        v4f* o = reinterpret_cast<v4f*>(obs) + (size_t)base * 175 / 4;
+        const v4f t = {acc, 1.f, 0.f, 1.f};
+        const int nq = nb * 175 / 4;
+        for (int q = tid; q < nq; q += 256) __builtin_nontemporal_store(t, o + q);
+    }
+    if (acc == 123456.789f) sink[tid] = acc;
+}
+
+static void run_cells(float* maps, float* recs, float* obs, float* sink, int n, int iters, int epb) {
+    hipEvent_t a, b;
+    CK(hipEventCreate(&a)); CK(hipEventCreate(&b));
+    const int blocks = (n + epb - 1) / epb;
+    const char* mn[6] = {"r", "rw", "r+obs", "rw+obs", "r+rec+obs", "rw+rec+obs"};
+    for (int mode = 0; mode < 6; ++mode) {
+        float ms = 0.f;
+        for (int rep = 0; rep < 2; ++rep) {
+            CK(hipEventRecord(a));
+            for (int i = 0; i < iters; ++i) {
+                const uint32_t seed = 77u + 1000u * i;
+                if (mode == 0) hipLaunchKernelGGL((cell_kernel<false, false, false>), dim3(blocks), dim3(256), 0, 0, maps, recs, obs, sink, n, seed, epb);
+                if (mode == 1) hipLaunchKernelGGL((cell_kernel<true, false, false>), dim3(blocks), dim3(256), 0, 0, maps, recs, obs, sink, n, seed, epb);
+                if (mode == 2) hipLaunchKernelGGL((cell_kernel<false, true, false>), dim3(blocks), dim3(256), 0, 0, maps, recs, obs, sink, n, seed, epb);
+                if (mode == 3) hipLaunchKernelGGL((cell_kernel<true, true, false>), dim3(blocks), dim3(256), 0, 0, maps, recs, obs, sink, n, seed, epb);
+                if (mode == 4) hipLaunchKernelGGL((cell_kernel<false, true, true>), dim3(blocks), dim3(256), 0, 0, maps, recs, obs, sink, n, seed, epb);
+                if (mode == 5) hipLaunchKernelGGL((cell_kernel<true, true, true>), dim3(blocks), dim3(256), 0, 0, maps, recs, obs, sink, n, seed, epb);
+            }
+            CK(hipEventRecord(b)); CK(hipEventSynchronize(b));
+            CK(hipEventElapsedTime(&ms, a, b));
+        }
+        printf("{\"layout\": \"t64cell\", \"mode\": \"%s\", \"epb\": %d, \"us\": %.1f}\n", mn[mode], epb, ms * 1000.0 / iters);
+        fflush(stdout);
+    }
+}
+
 template <int LAYOUT>
 static void run(const char* name, float* maps, float* obs, float* sink, int n, int iters, int epb) {
     using L = Lay<LAYOUT>;
@@ -132,11 +192,16 @@ int main(int argc, char** argv) {
     CK(hipMalloc(&obs, (size_t)n * 700 + 4096));
     CK(hipMalloc(&sink, 4096));
     CK(hipMemset(maps, 0, (size_t)n * 1920));
+    float* recs;
+    CK(hipMalloc(&recs, (size_t)n * 112 + 4096));
+    CK(hipMemset(recs, 0, (size_t)n * 112));
+    const bool all = argc > 3;
     for (int epb : {32, 64, 128}) {
-        run<0>("row", maps, obs, sink, n, iters, epb);
-        run<1>("t32", maps, obs, sink, n, iters, epb);
+        if (all) run<0>("row", maps, obs, sink, n, iters, epb);
+        if (all) run<1>("t32", maps, obs, sink, n, iters, epb);
         run<2>("t64", maps, obs, sink, n, iters, epb);
-        run<3>("t128", maps, obs, sink, n, iters, epb);
+        if (all) run<3>("t128", maps, obs, sink, n, iters, epb);
+        run_cells(maps, recs, obs, sink, n, iters, epb);
     }
     // the obs stream alone, for reference
     return 0;
