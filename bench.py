@@ -84,10 +84,21 @@ def cpu_baseline(workload, G, layout_codes, budget_s=12.0):
     def c_leg(n, nthreads, seconds):
         s = state(n)
         O.set_threads(nthreads)
-        steps, dt = _timed_loop(lambda t: O.step_v0(p, lay, s["acts"][t & 7], s["ball"], s["sc"], s["rew"], s["done"],
+        pp, ll, what = p, lay, "shared layout"
+        if workload == "c5":
+            # per-env random mazes as the GPU workload has them, the ball placed by the oracle's reset
+            n = min(n, 1 << 15)
+            s = state(n)
+            ll = np.where(rs.rand(n, G, G) < 0.25, ord("W"), ord("B")).astype(np.uint8)
+            ll[:, 0, :] = ll[:, -1, :] = ll[:, :, 0] = ll[:, :, -1] = ord("W")
+            free = np.where(ll.reshape(n, -1) == ord("B"), rs.rand(n, G * G), -1.0)
+            ll.reshape(n, -1)[np.arange(n), free.argmax(1)] = ord("X")
+            pp, what = O.params(O.VARIANT_V0, G, O.LAYOUT_PER_ENV), "per-env random layouts"
+            O.reset(pp, ll, None, 7, 0, s["ball"], None, s["sc"], s["rew"], s["done"], None)
+        steps, dt = _timed_loop(lambda t: O.step_v0(pp, ll, s["acts"][t & 7], s["ball"], s["sc"], s["rew"], s["done"],
                                                     s["gc"], s["obs"]), seconds)
-        return n * steps / dt, "%d envs x %d steps of the same %dx%d v0 workload, C oracle (OpenMP, %d thread%s), %.1f s" % (
-            n, steps, G, G, nthreads, "" if nthreads == 1 else "s", dt)
+        return n * steps / dt, "%d envs x %d steps of the same %dx%d v0 workload (%s), C oracle (OpenMP, %d thread%s), %.1f s" % (
+            n, steps, G, G, what, nthreads, "" if nthreads == 1 else "s", dt)
 
     v, sample = c_leg(N, threads, 0.6 * budget_s)
     out = {"value": v, "unit": "env-steps/s", "cores": threads, "kind": "port", "sample": sample}
@@ -111,18 +122,25 @@ def reference_interpreter(workload):
                       "1 core of a Xeon @ 2.1 GHz, NOT this box (the reference cannot travel to the GPU box)"}
 
 
-# algorithmic HBM bytes per env-step of the foveal variants: per-env scalars read + written,
-# the float32 [C,5,5] observation written, and for v4 the 18x18 float32 visit map read + written
-FOVEAL_BYTES = {"v1": 28 + 26 + 400, "v2": 28 + 17 + 500, "v4": 28 + 17 + 2 * 1296 + 700}
+# algorithmic HBM bytes per env-step of the foveal variants: per-env scalars read + written and the
+# float32 [C,5,5] observation written.  v4 (round 3: clock-relative visit map, a step touches only the window): scalars
+# 32 read (action 4, ball 8, step count 4, layout id 4, goal 8, visit clock 4) + 21 written (ball 8, step count 4, reward
+# 4, done 1, visit clock 4), observation 700, the 25 cells of the current window read + written (200) and the cells the
+# "previous" window shows beside them, read once each -- COUNTED over the timed steps (V4_PREV_ONLY_CELL per cell), as the
+# v5 events are; with --auto-reset a reset writes the zeroed map (4 G^2) and the placement (V4_RESET).  Round 2 streamed
+# the whole map twice: 28 + 17 + 700 + 2 x 1296 = 3 337.
+FOVEAL_BYTES = {"v1": 28 + 26 + 400, "v2": 28 + 17 + 500, "v4": 32 + 21 + 700 + 200}
+V4_PREV_ONLY_CELL, V4_RESET = 4, 12 + 1296
 FOVEAL_ACTIONS = {"v1": 4, "v2": 25, "v4": 25, "v5": 4}
 # v5 two-level step (lmaze_v5_hier_step).  Every env-step: reads action 4 + planner goal 4 + done 1 +
 # localDone 1 + ball 8 + layout id 4 + goal 8 + foveal goal 4 + fovea 16 + previous ball 8 + last window 8 + foveal
-# goal cell 8 + two step counts 8 = 82; writes ball 8 + previous ball 8 + fovea_0 8 + last window 8 + step count 4 +
-# two rewards 8 + two done flags 2 = 46; both observations written, 700 + 400.  Per event: plannerStep (the env
-# entered with localDone or done) writes 24; reset (entered with done) writes 12 + the zeroed visit map 1296; an
-# env that ends the step with localDone has its visit map read + written (2 x 1296; written only when it was
-# reset in the same launch, counted there); every other env has the two 5x5 windows of its map gathered, 200.
-V5_BASE, V5_PLAN, V5_RESET, V5_UPDATE, V5_GATHER = 82 + 46 + 1100, 24, 12 + 1296, 2 * 1296, 200
+# goal cell 8 + two step counts 8 + visit clock 4 = 86; writes ball 8 + previous ball 8 + fovea_0 8 + last window 8 + step
+# count 4 + two rewards 8 + two done flags 2 = 46; both observations written, 700 + 400; the 25 cells of the current
+# window and the 25 values of the "previous" one read, 200.  Per event: plannerStep (the env entered with localDone or
+# done) writes 24; reset (entered with done) writes 12 + the zeroed visit map 1296 + the previous-window record 100; an
+# env that ends the step with localDone writes the 25 updated cells, its previous-window record and its clock, 204.
+# (Round 2: 2 x 1296 per localDone and a 200-byte gather otherwise, 1 705 B per env-step on the same events.)
+V5_BASE, V5_PLAN, V5_RESET, V5_UPDATE = 86 + 46 + 1100 + 200, 24, 12 + 1296 + 100, 204
 
 
 def cpu_baseline_foveal(variant, budget_s=12.0):
@@ -402,16 +420,17 @@ def main():
         else:
             layout = pkg.layouts.to_codes(pkg.layouts.open_room(G, (G // 2, G // 2)))
         if args.per_env_layouts:
-            lgen = torch.Generator(device=dev).manual_seed(7 + rank)
-            lay = torch.where(torch.rand((N, G, G), device=dev, generator=lgen) < 0.25, ord("W"), ord("B")).to(torch.uint8)
-            lay[:, 0, :] = ord("W"); lay[:, -1, :] = ord("W"); lay[:, :, 0] = ord("W"); lay[:, :, -1] = ord("W")
-            lay[:, 1, 1] = ord("S")
-            lay[:, G - 2, G - 2] = ord("X")
+            # border 'W', interior walls i.i.d. p = 0.25 (Philox seed 7), 'X' on a uniformly chosen free
+            # cell, the ball on another (reset(): uniform over the cells that are neither 'W' nor 'X')
+            lay = pkg.layouts.random_walled(N, G, dev, p_wall=0.25, seed=7 + rank)
             env = pkg.LmazeVecEnv(N, variant="v0", per_env_layouts=lay, device=dev, seed=1, env_base=env_base)
-            workload = "%d x %dx%d mazes per GPU, v0 rules, per-env random layouts (p_wall 0.25), compact int32 obs" % (N, G, G)
+            workload = ("%d x %dx%d mazes per GPU, v0 rules, per-env random layouts (border 'W', interior walls i.i.d. p 0.25, "
+                        "Philox seed 7+rank, 'X' on a uniformly chosen free cell, ball on another), compact int32 obs" % (N, G, G))
         else:
             env = pkg.LmazeVecEnv(N, variant="v0", layout=layout, device=dev, seed=1, env_base=env_base)
-            workload = "%d x %dx%d mazes per GPU, v0 rules, shared open-room layout, compact int32 obs" % (N, G, G)
+            workload = "%d x %dx%d mazes per GPU, v0 rules, shared layout: %s, compact int32 obs" % (
+                N, G, G, "the 8x8 literal of lmaze_env.py:28-35 with a 'W' border" if args.workload == "c2" and G == 8
+                else "open room with a 'W' border, 'S' at (1,1), 'X' at (%d,%d)" % (G // 2, G // 2))
 
         actions = torch.randint(0, 4, (R, N), dtype=torch.int32, device=dev, generator=gen)
         row_ptr = [actions[r].data_ptr() for r in range(R)]
@@ -438,7 +457,7 @@ def main():
     with torch.cuda.device(dev):
         run(0, args.warmup)
         torch.cuda.synchronize()
-        if hier:       # the event counts of the timed steps come from a replay of exactly these steps (below)
+        if hier or args.workload == "v4":   # the event counts of the timed steps come from a replay of exactly these steps (below)
             snap = env.snapshot()
         if dist is not None:
             dist.barrier()
@@ -500,19 +519,40 @@ def main():
                 upd = env.foveal_done
                 cnt += torch.stack([plan.sum(), fresh.sum(), (upd & ~fresh).sum(), (~upd & ~fresh).sum(), upd.sum()])
         v5_events = dict(zip(("planner_steps", "resets", "visit_updates", "window_gathers", "local_dones"), cnt.tolist()))
+    v4_events = None
+    if args.workload == "v4" and rank == 0:
+        # the same for v4: cells the "previous" window shows beside the current one (25 - overlap of the two 5x5 windows,
+        # from the ball before and after each step) and, with --auto-reset, the resets
+        env.restore(snap)
+        cnt = torch.zeros(2, dtype=torch.int64, device=dev)
+        with torch.cuda.device(dev):
+            for t in range(args.warmup, args.warmup + args.steps):
+                before, fresh = env.ball_xy.clone(), env.done.clone()
+                env.step_raw(row_ptr[t % R], auto_reset=args.auto_reset)
+                d = (env.ball_xy - before).abs().clamp(max=5)
+                only = 25 - (5 - d[:, 0]) * (5 - d[:, 1])
+                if args.auto_reset:
+                    only = torch.where(fresh, torch.zeros_like(only), only)     # a reset shows the same window twice
+                cnt += torch.stack([only.sum(), fresh.sum() if args.auto_reset else fresh.sum() * 0])
+        v4_events = dict(zip(("previous_only_cells", "resets"), cnt.tolist()))
 
     ceiling = measured_ceiling(pkg, env.obs.numel() * 4, dev) if rank == 0 else None
 
     if rank == 0:
         if hier:
             ev = v5_events
-            B = V5_BASE + (V5_PLAN * ev["planner_steps"] + V5_RESET * ev["resets"] + V5_UPDATE * ev["visit_updates"]
-                           + V5_GATHER * ev["window_gathers"]) / float(N * args.steps)
+            B = V5_BASE + (V5_PLAN * ev["planner_steps"] + V5_RESET * ev["resets"] + V5_UPDATE * ev["local_dones"]) / float(N * args.steps)
+        elif args.workload == "v4":
+            B = FOVEAL_BYTES["v4"] + (V4_PREV_ONLY_CELL * v4_events["previous_only_cells"]
+                                      + V4_RESET * v4_events["resets"]) / float(N * args.steps)
         else:
             B = FOVEAL_BYTES[args.workload] if foveal else bytes_per_env_step(G, args.per_env_layouts)
         total_steps = world * N * args.steps
         value = total_steps / elapsed
-        achieved = N * B / (kern_ms * 1e-3) / 1e9
+        # ONE clock: achieved / frac follow from the line's own ms_per_step (host wall time around the timed launches,
+        # max over ranks; every GPU moves N * B bytes per step); the HIP-event figure of rank 0 sits beside it
+        achieved = N * B / (elapsed / args.steps) / 1e9
+        achieved_events = N * B / (kern_ms * 1e-3) / 1e9
         traffic, traffic_source = None, None
         tpath = os.path.join(ROOT, "profiles", "traffic.json")
         if os.path.exists(tpath):
@@ -529,18 +569,20 @@ def main():
                                       % (key, rec.get("round"), rec.get("files", "profiles/r%02d/" % int(rec.get("round", 1)))))
             except Exception:
                 traffic, traffic_source = None, None
+        # the kernel and policy the launcher actually picks for this shape and hint (lmaze_describe_*: the launcher's own
+        # decision code, nothing queued)
+        abi = importlib.import_module(pkg.__name__ + "._abi")
         if foveal:
-            kernel = "lmaze::foveal_kernel<%s, FM_STEP%s>" % (args.workload, ", hier" if hier else "")
+            kernel = "lmaze::" + abi.describe_foveal_step(env.params, N, auto_reset=bool(args.auto_reset) or hier)
             perenv_kernel = None
-        elif args.per_env_layouts:
-            wave = (G * G) % 256 == 0
-            kernel = "lmaze::step_perenv_%skernel<%d, v0>" % ("wave_" if wave else "", G)
-            # BASELINE config 5 names an LDS-tiled maze per workgroup; at G*G a multiple of 256 the register-tiled
-            # one-wave-per-env kernel is used instead because it measured faster (0.873 vs 0.96 ms)
-            perenv_kernel = ("wave/register-tiled (one wave per env, layout in registers; measured faster than the LDS-tiled "
-                             "kernel at this G)" if wave else "LDS-tiled (a workgroup tiles ~16 KiB of layouts)")
         else:
-            kernel, perenv_kernel = "lmaze::step_shared_kernel<%d, v0>" % G, None
+            kernel = "lmaze::" + abi.describe_step(env.params, N, auto_reset=bool(args.auto_reset))
+            perenv_kernel = None
+            if args.per_env_layouts:
+                # BASELINE config 5 names an LDS-tiled maze per workgroup; at G*G a multiple of 256 the register-tiled
+                # one-wave-per-env kernel is used instead because it measured faster (0.873 vs 0.96 ms)
+                perenv_kernel = ("wave/register-tiled (one wave per env, layout in registers; measured faster than the LDS-tiled "
+                                 "kernel at this G)" if "perenv_wave" in kernel else "LDS-tiled (a workgroup tiles ~8 KiB of layouts)")
         out = {
             "metric": "env steps/sec (whole node), 1M parallel 11x11 mazes at 1/2/4/8 MI355X" if args.workload == "c3" and N == (1 << 20)
                       else "env steps/sec (whole node); workload '%s', NOT the configuration BASELINE.json's metric is quoted on" % args.workload,
@@ -567,11 +609,17 @@ def main():
                                        for k, v in (tuned or {}).items()}},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_source,
-                         "kernel": kernel, "bytes_per_env_step": B, "kernel_ms_avg": kern_ms, "measured_ceiling": ceiling},
+                         "kernel": kernel, "bytes_per_env_step": B, "kernel_ms_avg": kern_ms,
+                         "achieved_events": achieved_events, "frac_events": achieved_events / HBM_PEAK_GBS,
+                         "clock": "achieved / frac: ms_per_step (perf_counter around the timed launches, max over ranks); "
+                                  "achieved_events / frac_events / kernel_ms_avg: HIP events on rank 0's launch stream",
+                         "measured_ceiling": ceiling},
         }
         if hier:
             out["config"]["v5_events_in_timed_steps"] = v5_events
             out["config"]["local_done_rate"] = v5_events["local_dones"] / float(N * args.steps)
+        if v4_events is not None:
+            out["config"]["v4_events_in_timed_steps"] = v4_events
         if not args.no_cpu_baseline and world == 1:      # rank 0 at N=1 only
             out["cpu_baseline"] = (cpu_baseline_foveal(args.workload, args.cpu_baseline_seconds) if foveal
                                    else cpu_baseline(args.workload, G, layout, args.cpu_baseline_seconds))

@@ -30,7 +30,8 @@ SYMBOLS = ("lmaze_abi_version", "lmaze_strerror", "lmaze_device_info", "lmaze_st
            "lmaze_step_v0_autoreset", "lmaze_step_v3_autoreset", "lmaze_observe", "lmaze_reset",
            "lmaze_episode_stats", "lmaze_bandwidth_probe", "lmaze_render_expanded", "lmaze_foveal_step", "lmaze_foveal_step_autoreset", "lmaze_foveal_reset", "lmaze_v1_set_foveal_goal",
            "lmaze_v5_planner_step", "lmaze_v5_hier_step", "lmaze_v6_safe_foveal_goal", "lmaze_expand_planes",
-           "lmaze_foveal_visit_bytes", "lmaze_foveal_materialise_visit", "lmaze_foveal_load_visit")
+           "lmaze_foveal_visit_bytes", "lmaze_foveal_materialise_visit", "lmaze_foveal_load_visit",
+           "lmaze_describe_step", "lmaze_describe_foveal_step")
 
 
 class LmazeParams(C.Structure):
@@ -136,6 +137,10 @@ def _load():
     lib.lmaze_foveal_materialise_visit.argtypes = [FP, FB, vp, i64, vp]
     lib.lmaze_foveal_load_visit.restype = C.c_int
     lib.lmaze_foveal_load_visit.argtypes = [FP, FB, vp, i64, vp]
+    lib.lmaze_describe_step.restype = C.c_int
+    lib.lmaze_describe_step.argtypes = [P, i64, i32, i32, C.c_char_p, i32]
+    lib.lmaze_describe_foveal_step.restype = C.c_int
+    lib.lmaze_describe_foveal_step.argtypes = [FP, i64, i32, C.c_char_p, i32]
     if lib.lmaze_abi_version() != ABI_VERSION:
         raise ImportError("liblmaze_hip.so ABI %d != binding %d: rebuild" % (lib.lmaze_abi_version(), ABI_VERSION))
     return lib
@@ -158,6 +163,19 @@ def device_info(device=0):
     name = C.create_string_buffer(64)
     check("lmaze_device_info", lib.lmaze_device_info(int(device), C.byref(cu), name, 64))
     return {"cu_count": cu.value, "arch": name.value.decode("ascii", "replace")}
+
+
+def describe_step(params, n, auto_reset=False, with_obs=True):
+    """The kernel / grid / launch policy the library would queue for n envs with these LmazeParams (lmaze_describe_step)."""
+    buf = C.create_string_buffer(256)
+    check("lmaze_describe_step", lib.lmaze_describe_step(C.byref(params), int(n), 1 if auto_reset else 0, 1 if with_obs else 0, buf, 256))
+    return buf.value.decode("ascii", "replace")
+
+
+def describe_foveal_step(params, n, auto_reset=False):
+    buf = C.create_string_buffer(256)
+    check("lmaze_describe_foveal_step", lib.lmaze_describe_foveal_step(C.byref(params), int(n), 1 if auto_reset else 0, buf, 256))
+    return buf.value.decode("ascii", "replace")
 
 
 def make_params(variant, grid, layout_mode, step_limit, reward_wall, reward_move, reward_goal):

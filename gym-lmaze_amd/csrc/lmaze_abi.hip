@@ -1,6 +1,7 @@
 // lmaze_abi.hip -- the extern "C" surface declared in include/lmaze.h: argument checks and
 // launches only.  No allocation, no synchronisation, no host-side compute fallback: if the
 // launch fails the hipError_t goes back to the caller.
+#include <stdio.h>
 #include <string.h>
 
 #include "lmaze_common.h"
@@ -47,7 +48,28 @@ static StepArgs make_args(const LmazeParams* p, const uint8_t* layout, const int
     a.goal_rw = nullptr;
     a.mask = nullptr;
     a.launch_hint = p->launch_hint;
+    a.info = nullptr;
     return a;
+}
+
+namespace lmaze {
+void describe_launch(LaunchInfo* info, const char* kernel, int epb, int per_cu, int chunks, bool nt, int64_t grid, int block, size_t lds) {
+    snprintf(info->kernel, sizeof(info->kernel), "%s", kernel);
+    info->envs_per_workgroup = epb;
+    info->workgroups_per_cu = per_cu;
+    info->chunks = chunks;
+    info->non_temporal = nt ? 1 : 0;
+    info->grid = grid;
+    info->block = block;
+    info->lds = (int64_t)lds;
+}
+}  // namespace lmaze
+
+static int format_launch(const LaunchInfo& i, char* text, int32_t len) {
+    if (!text || len < 1) return LMAZE_E_NULL;
+    snprintf(text, (size_t)len, "%s grid=%lld block=%d lds=%lld envs_per_workgroup=%d workgroups_per_cu=%d chunks=%d", i.kernel,
+             (long long)i.grid, i.block, (long long)i.lds, i.envs_per_workgroup, i.workgroups_per_cu, i.chunks);
+    return 0;
 }
 
 extern "C" {
@@ -83,6 +105,26 @@ int lmaze_device_info(int device, int32_t* cu_count_host, char* name_host, int32
         name_host[name_len - 1] = 0;
     }
     return 0;
+}
+
+int lmaze_describe_step(const LmazeParams* params, int64_t n, int32_t auto_reset, int32_t with_obs, char* text_host,
+                        int32_t len) {
+    int rc = check_params(params, n);
+    if (rc) return rc;
+    if (params->variant != LMAZE_VARIANT_V0 && params->variant != LMAZE_VARIANT_V3) return LMAZE_E_VARIANT;
+    if (!text_host || len < 1) return LMAZE_E_NULL;
+    text_host[0] = 0;
+    if (n == 0) return 0;
+    LaunchInfo info;
+    memset(&info, 0, sizeof(info));
+    // nothing is dereferenced: the launcher fills `info` where it would have queued the kernel
+    StepArgs a = make_args(params, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr,
+                           with_obs ? reinterpret_cast<int32_t*>(16) : nullptr, n);
+    a.auto_reset = auto_reset ? 1 : 0;
+    a.info = &info;
+    rc = (int)launch_step(params->variant, true, a, params->layout_mode, nullptr);
+    if (rc) return rc;
+    return format_launch(info, text_host, len);
 }
 
 int lmaze_step_v0(const LmazeParams* params, const uint8_t* layout, const int32_t* action, int32_t* ball_xy,

@@ -11,6 +11,15 @@
 
 namespace lmaze {
 
+// What a launcher decided, for lmaze_describe_step / lmaze_describe_foveal_step (include/lmaze.h): filled INSTEAD of
+// launching when the args carry a pointer to one, by the very code that launches otherwise.
+struct LaunchInfo {
+    char kernel[96];
+    int32_t envs_per_workgroup, workgroups_per_cu, chunks, non_temporal, block;
+    int64_t grid, lds;
+};
+void describe_launch(LaunchInfo* info, const char* kernel, int epb, int per_cu, int chunks, bool nt, int64_t grid, int block, size_t lds);
+
 // Everything a step/observe launch needs, passed by value in the kernarg segment.
 struct StepArgs {
     const uint8_t* layout;  // [G*G] shared or [N*G*G] per env, reference cell characters
@@ -39,6 +48,7 @@ struct StepArgs {
     int2* goal_rw;           // v3 + auto_reset: the goal array, writable
     const uint8_t* mask;     // observe only: re-render just the envs with mask != 0 (null = all)
     int32_t launch_hint;     // LmazeParams.launch_hint (0 = library default policy)
+    LaunchInfo* info;        // host pointer; non-null: describe the launch instead of queueing it
 };
 
 // masked on-device reset (lmaze_aux.hip)

@@ -13,6 +13,9 @@
 // reference halves the whole G x G plane on every update (v4:211-214, v5:313-318); here that is `clock += 1` and a
 // step only gathers the 2 x 2 tiles (4 x 4 cells, 64 B each) under the window it shows, adds, and writes them back.
 // HBM bytes per env-step: v1 454, v2 545, v4 about 1 000 instead of round 2's 3 337.
+#include <cstdio>
+#include <cstring>
+
 #include "lmaze_common.h"
 #include "lmaze_visit.h"
 
@@ -48,6 +51,7 @@ struct FovealArgs {
     uint64_t* epoch_out;
     int32_t nt;             // non-temporal observation stores (set by the launcher)
     int32_t auto_reset;     // step: an env whose done flag is set on entry is reset first (v1, v2, v4)
+    LaunchInfo* info;       // host pointer; non-null: describe the launch instead of queueing it (lmaze_describe_foveal_step)
 };
 
 struct EnvRec {           // one env after its transition (registers only; phase 1 turns it into plane masks)
@@ -990,7 +994,13 @@ __global__ __launch_bounds__(LMAZE_BLOCK) LMAZE_FOVEAL_ATTR void foveal_kernel(c
             if (flags[le] & 1) continue;
             float v[4];
             nibble_floats(lbits, q, v);
-            reinterpret_cast<float4*>(loc)[q] = make_float4(v[0], v[1], v[2], v[3]);
+            if (a.nt) {   // streamed like the foveal observation (round 3: these 400 B per env were plain stores)
+                typedef float v4f __attribute__((ext_vector_type(4)));
+                v4f t = {v[0], v[1], v[2], v[3]};
+                __builtin_nontemporal_store(t, reinterpret_cast<v4f*>(loc) + q);
+            } else {
+                reinterpret_cast<float4*>(loc)[q] = make_float4(v[0], v[1], v[2], v[3]);
+            }
         }
     }
     chunk += gridDim.x;
@@ -1195,6 +1205,15 @@ static hipError_t launch_foveal_one(const FovealArgs& a, hipStream_t s) {
         if (want > lds && want <= lds_limit()) lds = want;     // per_cu 1 (120 KiB) and 2 (66 KiB) included where the device allows
     }
     const dim3 grid((unsigned)blocks), block(LMAZE_BLOCK);
+    if (a.info) {
+        char name[96];
+        snprintf(name, sizeof(name), "foveal_kernel<v%d, %s, %d, %d, %s>", VARIANT,
+                 MODE == FM_STEP ? "step" : (MODE == FM_RESET ? "reset" : (MODE == FM_SETGOAL ? "setgoal" : "planner")), EPB,
+                 (a.p.grid == 18 || a.p.grid == 14) ? a.p.grid : 0, a.auto_reset ? "fused-reset" : "plain");
+        describe_launch(a.info, name, EPB, (MODE == FM_STEP && per_cu >= 1 && per_cu <= 8 && lds > (size_t)EPB * 64) ? per_cu : 0, m, b.nt != 0,
+                        blocks, LMAZE_BLOCK, lds);
+        return hipSuccess;
+    }
     if constexpr (MODE == FM_STEP) {
         if (a.auto_reset) {
             if (a.p.grid == 18) hipLaunchKernelGGL((foveal_kernel<VARIANT, MODE, EPB, 18, true>), grid, block, lds, s, b);
@@ -1226,7 +1245,7 @@ template <int MODE>
 static hipError_t launch_foveal_mode(const FovealArgs& a0, hipStream_t s) {
     if (a0.n == 0) return hipSuccess;
     FovealArgs a = a0;
-    if (MODE == FM_STEP && a.p.launch_hint == 0 && !a.auto_reset) {
+    if (MODE == FM_STEP && a.p.launch_hint == 0 && (!a.auto_reset || a.p.variant == LMAZE_VARIANT_V5 || a.p.variant == LMAZE_VARIANT_V6)) {
         // Default policy of the plain step in the streaming regime (observation larger than the Infinity Cache), as a
         // hint.  Round 2, after workgroups learnt to take several chunks: on a box where every uncapped one-chunk launch of
         // v1 sat at 78.5 us whatever the envs per workgroup (on other boxes 32 envs: 66.8-67.4), 32 envs x 3 chunks ran
@@ -1236,7 +1255,10 @@ static hipError_t launch_foveal_mode(const FovealArgs& a0, hipStream_t s) {
         if ((size_t)a.n * C * W25 * 4 > kFovealStreamBytes) {
             if (a.p.variant == LMAZE_VARIANT_V1) a.p.launch_hint = 0x220;
             else if (a.p.variant == LMAZE_VARIANT_V2) a.p.launch_hint = 0x35;
-            else if (a.p.variant == LMAZE_VARIANT_V4) a.p.launch_hint = 0x120;
+            // round 3 (window-only visit map): v4 128 envs per workgroup 305.8 us, 64 envs 311.2 (x 2 chunks 321, at 5 per
+            // CU 308.7), 32 envs 406; v5/v6 128 envs 446-449 (x 2 chunks 446), 64 envs 503-511
+            else if (a.p.variant == LMAZE_VARIANT_V4) a.p.launch_hint = 0x40;
+            else a.p.launch_hint = 0x40;
         }
     }
     if (MODE == FM_STEP) {
@@ -1343,6 +1365,7 @@ static FovealArgs make_foveal_args(const LmazeFovealParams* p, const uint8_t* la
     a.epoch_out = nullptr;
     a.nt = 0;
     a.auto_reset = 0;
+    a.info = nullptr;
     return a;
 }
 
@@ -1458,6 +1481,30 @@ int lmaze_v6_safe_foveal_goal(const LmazeFovealParams* params, const uint8_t* la
     hipLaunchKernelGGL(safe_goal_kernel, dim3((unsigned)((n + LMAZE_BLOCK - 1) / LMAZE_BLOCK)), dim3(LMAZE_BLOCK), 0,
                        (hipStream_t)stream, a, out_goal);
     return (int)hipGetLastError();
+}
+
+int lmaze_describe_foveal_step(const LmazeFovealParams* params, int64_t n, int32_t auto_reset, char* text_host, int32_t len) {
+    if (!params || !text_host || len < 1) return LMAZE_E_NULL;
+    const bool v56 = params->variant == LMAZE_VARIANT_V5 || params->variant == LMAZE_VARIANT_V6;
+    if (params->variant != LMAZE_VARIANT_V1 && params->variant != LMAZE_VARIANT_V2 && params->variant != LMAZE_VARIANT_V4 && !v56)
+        return LMAZE_E_VARIANT;
+    if (params->grid < FOV || params->grid > LMAZE_MAX_GRID) return LMAZE_E_GRID;
+    if (params->n_layouts < 1 || params->n_layouts > LMAZE_MAX_LAYOUTS) return LMAZE_E_LAYOUT;
+    if (n < 0 || n > LMAZE_MAX_ENVS) return LMAZE_E_COUNT;
+    text_host[0] = 0;
+    if (n == 0) return 0;
+    LaunchInfo info;
+    memset(&info, 0, sizeof(info));
+    LmazeFovealBuffers none;
+    memset(&none, 0, sizeof(none));
+    FovealArgs a = make_foveal_args(params, nullptr, &none, n);     // nothing is dereferenced: the launcher fills `info`
+    a.auto_reset = auto_reset ? 1 : 0;
+    a.info = &info;
+    const int rc = (int)launch_foveal_mode<FM_STEP>(a, nullptr);
+    if (rc) return rc;
+    snprintf(text_host, (size_t)len, "%s grid=%lld block=%d lds=%lld envs_per_workgroup=%d workgroups_per_cu=%d chunks=%d", info.kernel,
+             (long long)info.grid, info.block, (long long)info.lds, info.envs_per_workgroup, info.workgroups_per_cu, info.chunks);
+    return 0;
 }
 
 int64_t lmaze_foveal_visit_bytes(int32_t grid, int64_t n) {

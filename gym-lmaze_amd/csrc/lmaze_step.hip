@@ -19,6 +19,8 @@
 //   auto_reset  an env whose done flag is set on entry is first re-placed exactly as
 //               lmaze_reset(mask = done) would (reference reset(), lmaze_env.py:64-110)
 //   mask        (observe only) re-render just the envs a masked reset touched
+#include <cstdio>
+
 #include "lmaze_common.h"
 
 namespace lmaze {
@@ -843,6 +845,12 @@ static hipError_t launch_shared(const StepArgs& a, hipStream_t s) {
     if (m == 0) m = nt ? def_m : 1;
     const int64_t grid = (blocks + m - 1) / m;
     if (!grid_ok(grid)) return hipErrorInvalidConfiguration;
+    if (a.info) {
+        char name[96];
+        snprintf(name, sizeof(name), "step_shared_kernel<%d, v%d, %s, %d, %s>", GT, VARIANT, DO_STEP ? "step" : "observe", EPB, nt ? "nt" : "plain");
+        describe_launch(a.info, name, EPB, per_cu >= 1 && per_cu < 8 ? per_cu : 0, m, nt, grid, LMAZE_BLOCK, lds);
+        return hipSuccess;
+    }
     if (nt)
         hipLaunchKernelGGL((step_shared_kernel<GT, VARIANT, DO_STEP, EPB, true>), dim3((unsigned)grid),
                            dim3(LMAZE_BLOCK), lds, s, a);
@@ -863,6 +871,12 @@ static hipError_t launch_perenv_wave(const StepArgs& a, hipStream_t s) {
     const int64_t blocks = (a.n + per_block - 1) / per_block;
     const bool nt = a.obs != nullptr && (size_t)a.n * G * G * 4 > kNonTemporalObsBytes;
     if (!grid_ok(blocks)) return hipErrorInvalidConfiguration;
+    if (a.info) {
+        char name[96];
+        snprintf(name, sizeof(name), "step_perenv_wave_kernel<%d, v%d, %s, %s>", G, VARIANT, DO_STEP ? "step" : "observe", nt ? "nt" : "plain");
+        describe_launch(a.info, name, (int)per_block, 0, 1, nt, blocks, LMAZE_BLOCK, 0);
+        return hipSuccess;
+    }
     if (nt)
         hipLaunchKernelGGL((step_perenv_wave_kernel<G, VARIANT, DO_STEP, true>), dim3((unsigned)blocks),
                            dim3(LMAZE_BLOCK), 0, s, b);
@@ -887,6 +901,12 @@ static hipError_t launch_perenv(const StepArgs& a, hipStream_t s) {
     b.envs_per_block = perenv_envs_per_block(a.grid, 8192);
     const int64_t blocks = (a.n + b.envs_per_block - 1) / b.envs_per_block;
     if (!grid_ok(blocks)) return hipErrorInvalidConfiguration;
+    if (a.info) {
+        char name[96];
+        snprintf(name, sizeof(name), "step_perenv_kernel<%d, v%d, %s>", GT, VARIANT, DO_STEP ? "step" : "observe");
+        describe_launch(a.info, name, b.envs_per_block, 0, 1, false, blocks, LMAZE_BLOCK, perenv_lds_bytes(a.grid, b.envs_per_block));
+        return hipSuccess;
+    }
     hipLaunchKernelGGL((step_perenv_kernel<GT, VARIANT, DO_STEP>), dim3((unsigned)blocks), dim3(LMAZE_BLOCK),
                        perenv_lds_bytes(a.grid, b.envs_per_block), s, b);
     return hipGetLastError();
@@ -916,6 +936,12 @@ static hipError_t launch_one(const StepArgs& a, int layout_mode, hipStream_t s) 
             const int64_t blocks = (waves + wpb - 1) / wpb;
             if (!grid_ok(blocks)) return hipErrorInvalidConfiguration;
             const dim3 grid((unsigned)blocks), block(64 * wpb);
+            if (a.info) {
+                char name[96];
+                snprintf(name, sizeof(name), "step_shared_wave8_kernel<v%d, %s, %d>", VARIANT, DO_STEP ? "step" : "observe", epw);
+                describe_launch(a.info, name, epw * wpb, 0, 1, false, blocks, 64 * wpb, 0);
+                return hipSuccess;
+            }
             if (code == 1) hipLaunchKernelGGL((step_shared_wave8_kernel<VARIANT, DO_STEP, 64>), grid, block, 0, s, a);
             else if (code == 2) hipLaunchKernelGGL((step_shared_wave8_kernel<VARIANT, DO_STEP, 32>), grid, block, 0, s, a);
             else hipLaunchKernelGGL((step_shared_wave8_kernel<VARIANT, DO_STEP, 16>), grid, block, 0, s, a);

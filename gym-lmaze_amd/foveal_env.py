@@ -315,7 +315,7 @@ class LmazeFovealVecEnv(object):
 
     # launch policies autotune() tries: LmazeFovealParams.launch_hint = ((chunks per workgroup - 1) << 8) |
     # (envs-per-workgroup code << 4) | workgroups per CU
-    CANDIDATES = (0x00, 0x20, 0x26, 0x27, 0x30, 0x34, 0x35, 0x36, 0x43, 0x40, 0x120, 0x126, 0x220, 0x226, 0x130, 0x134)
+    CANDIDATES = (0x00, 0x20, 0x26, 0x30, 0x34, 0x35, 0x36, 0x43, 0x40, 0x45, 0x120, 0x220, 0x130, 0x134, 0x140, 0x145)
 
     def autotune(self, actions, goals=None, auto_reset=False, steps=24, candidates=None, warm=100, rounds=3,
                  placement_trials=0):

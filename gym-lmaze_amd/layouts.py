@@ -230,3 +230,26 @@ GRID_8_BORDERED = (
     "WBWBWBWW",
     "WWWWWWWW",
 )
+
+
+def random_walled(num_envs, G, device, p_wall=0.25, seed=7, block=1 << 17):
+    """Per-env random mazes of SURVEY 8(d) C5 as uint8[N,G,G] on `device`: a 'W' border, interior cells walls with
+    probability p_wall (i.i.d., torch's device generator is Philox, seed `seed`), 'X' on a uniformly chosen free cell of
+    each maze; every other free cell 'B'.  The ball goes to another free cell at reset() (lmaze_env.py:70-78: uniform
+    over the cells that are neither 'W' nor 'X').  Built in blocks of `block` envs to bound the scratch memory."""
+    import torch
+    gen = torch.Generator(device=device).manual_seed(int(seed))
+    out = torch.empty((num_envs, G, G), dtype=torch.uint8, device=device)
+    for lo in range(0, num_envs, block):
+        n = min(block, num_envs - lo)
+        lay = torch.where(torch.rand((n, G, G), device=device, generator=gen) < p_wall, ord("W"), ord("B")).to(torch.uint8)
+        lay[:, 0, :] = ord("W"); lay[:, -1, :] = ord("W"); lay[:, :, 0] = ord("W"); lay[:, :, -1] = ord("W")
+        score = torch.rand((n, G * G), device=device, generator=gen)
+        score = torch.where(lay.view(n, -1) == ord("B"), score, torch.full_like(score, -1.0))
+        pick = score.argmax(dim=1)
+        has_free = score.gather(1, pick[:, None])[:, 0] >= 0            # a maze without a free cell keeps no 'X'
+        flat = lay.view(n, -1)
+        rows = torch.nonzero(has_free)[:, 0]
+        flat[rows, pick[rows]] = ord("X")
+        out[lo:lo + n] = lay
+    return out

@@ -106,6 +106,16 @@ const char* lmaze_strerror(int code);
 int lmaze_device_info(int device, int32_t* cu_count_host, char* name_host, int32_t name_len);
 
 /*
+ * Which kernel, grid and launch policy lmaze_step_v0 / _v3 (auto_reset != 0: the *_autoreset forms) would queue for n
+ * envs with these params -- decided by the very code that launches, nothing is queued or dereferenced.  text_host
+ * receives one line, e.g. "step_shared_kernel<11, v0, step, 32, nt> grid=32768 block=256 lds=20480
+ * envs_per_workgroup=32 workgroups_per_cu=0 chunks=1" (workgroups_per_cu 0 = no cap).  For bench.py's
+ * roofline.kernel and the launch-policy guard test; no reference counterpart.
+ */
+int lmaze_describe_step(const LmazeParams* params, int64_t n, int32_t auto_reset, int32_t with_obs, char* text_host,
+                        int32_t len);
+
+/*
  * One step() of N v0 mazes: replaces v0:146-237 (action decode 153-170, collision and
  * position update 172-195, reward 174/184/194, done 246-249, plane build 208-215).
  *   action      int32[N]    0:(-1,0) 1:(+1,0) 2:(0,-1) 3:(0,+1), anything else (0,0)
@@ -307,6 +317,10 @@ typedef struct LmazeFovealBuffers {
  * second gather).  lmaze_foveal_visit_bytes() covers both.
  */
 int64_t lmaze_foveal_visit_bytes(int32_t grid, int64_t n);
+
+/* As lmaze_describe_step, for lmaze_foveal_step (auto_reset != 0: lmaze_foveal_step_autoreset; v5/v6:
+ * lmaze_v5_hier_step). */
+int lmaze_describe_foveal_step(const LmazeFovealParams* params, int64_t n, int32_t auto_reset, char* text_host, int32_t len);
 
 /* out float[N,G,G] = the reference's state[2] of every env (true values, row-major), from the clock-relative
  * tiles.  Off the step path (tests, LmazeEnv_v4.state, checkpoints). */

@@ -28,6 +28,8 @@ def _run(*flags, env=None):
     ("--workload", "v2", "--envs", "262144", "--steps", "8", "--warmup", "2", "--cpu-baseline-seconds", "0.5"),
     ("--workload", "c2", "--graph", "--auto-reset", "--steps", "10", "--warmup", "2", "--no-cpu-baseline"),
     ("--workload", "v5", "--envs", "262144", "--steps", "30", "--warmup", "12", "--cpu-baseline-seconds", "0.5"),
+    ("--workload", "v4", "--envs", "262144", "--steps", "12", "--warmup", "4", "--no-cpu-baseline"),
+    ("--workload", "v4", "--envs", "262144", "--steps", "12", "--warmup", "60", "--auto-reset", "--no-cpu-baseline"),
 ])
 def test_bench_line(flags):
     d = _run(*flags)
@@ -43,7 +45,12 @@ def test_bench_line(flags):
     r = d["roofline"]
     assert r["bound"] == "hbm" and r["unit"] == "GB/s" and r["peak"] == 8000.0
     assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-12 and 0.0 < r["frac"] < 1.0
-    assert abs(r["achieved"] - envs * r["bytes_per_env_step"] / (r["kernel_ms_avg"] * 1e-3) / 1e9) <= 1e-6 * r["achieved"]
+    # ONE clock: the roofline fraction follows from the line's own ms_per_step ...
+    per_gpu = envs // d["n_gpus"]
+    assert abs(r["frac"] - per_gpu * r["bytes_per_env_step"] / (d["ms_per_step"] * 1e-3) / 1e9 / r["peak"]) <= 0.005 * r["frac"]
+    # ... and the HIP-event figure sits beside it under its own name
+    assert abs(r["achieved_events"] - per_gpu * r["bytes_per_env_step"] / (r["kernel_ms_avg"] * 1e-3) / 1e9) <= 1e-6 * r["achieved_events"]
+    assert abs(r["frac_events"] - r["achieved_events"] / r["peak"]) < 1e-12 and "ms_per_step" in r["clock"]
     assert r["traffic"] is None or r["traffic"] >= 0.9 * (envs // d["n_gpus"]) * r["bytes_per_env_step"]
     assert set(r["measured_ceiling"]) >= {"fill", "copy", "unit"}
     if "--no-cpu-baseline" in flags:
@@ -65,13 +72,31 @@ def test_bench_line(flags):
     assert (r["traffic"] is None) == (r["traffic_source"] is None)
     if wl in ("v2", "v5"):          # the foveal workloads pick their launch policy before the timed region, as C3 does
         assert len(d["config"]["autotune_ms"]) >= 5 and ("0x%02x" % d["config"]["launch_hint"]) in d["config"]["autotune_ms"]
+    # roofline.kernel is what the launcher picked (lmaze_describe_step), and config.workload says what ran
+    k = r["kernel"]
+    assert k.startswith("lmaze::") and " grid=" in k and "envs_per_workgroup=" in k
+    if wl == "c2":
+        assert "step_shared_wave8_kernel<v0" in k and "8x8 literal" in d["config"]["workload"] and "open" not in d["config"]["workload"]
+    if wl == "c3":
+        assert "step_shared_kernel<11, v0, step" in k and "open room" in d["config"]["workload"]
     if wl == "c5":
-        assert "wave/register-tiled" in d["config"]["perenv_kernel"]
+        assert "wave/register-tiled" in d["config"]["perenv_kernel"] and "step_perenv_wave_kernel<32" in k
+        assert "uniformly chosen free cell" in d["config"]["workload"]
+    if wl in ("v2", "v5"):
+        assert "foveal_kernel<%s, step" % wl in k
     if wl == "v5":
         ev = d["config"]["v5_events_in_timed_steps"]
         total = d["config"]["envs_per_gpu"] * d["steps"]
         assert ev["resets"] + ev["visit_updates"] + ev["window_gathers"] == total and 0 < ev["resets"] < ev["planner_steps"] < total
+        # round 3: a step touches only the window -- about 1.46 KB per env-step on these events, not round 2's 1.7 KB
+        assert 1432 < r["bytes_per_env_step"] < 1560
         assert 0.05 < d["config"]["local_done_rate"] < 0.6           # the natural rate, not 1.0
+    if wl == "v4":
+        ev = d["config"]["v4_events_in_timed_steps"]
+        total = d["config"]["envs_per_gpu"] * d["steps"]
+        assert 5 * total < ev["previous_only_cells"] < 16 * total      # a uniform 25-way teleport leaves ~10 cells outside the overlap
+        assert (ev["resets"] > 0) == ("--auto-reset" in flags)
+        assert 953 + 20 < r["bytes_per_env_step"] < 953 + 64 + (60 if "--auto-reset" in flags else 0)
     if "--workload" not in flags:
         assert d["metric"].startswith("env steps/sec (whole node), 1M parallel 11x11 mazes")
         assert d["config"]["envs_per_gpu"] == 1 << 20 and d["config"]["grid"] == 11 and r["bytes_per_env_step"] == 521

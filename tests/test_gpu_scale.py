@@ -63,11 +63,13 @@ def test_c3_1m_11x11_vs_oracle_and_properties():
 def test_c5_1m_32x32_per_env_layouts():
     N, G = 1 << 20, 32
     gen = torch.Generator(device="cuda").manual_seed(7)
-    lay = torch.where(torch.rand((N, G, G), device="cuda", generator=gen) < 0.25, ord("W"), ord("B")).to(torch.uint8)
-    lay[:, 0, :] = ord("W"); lay[:, -1, :] = ord("W"); lay[:, :, 0] = ord("W"); lay[:, :, -1] = ord("W")
-    lay[:, 1, 1] = ord("S")
-    lay[:, G - 2, G - 2] = ord("X")
+    # SURVEY 8(d) C5 as bench.py builds it: 'X' on a uniformly chosen free cell of each maze, the ball on another
+    lay = PKG.layouts.random_walled(N, G, torch.device("cuda"), p_wall=0.25, seed=7)
+    assert int((lay == ord("X")).sum().item()) == N and bool((lay[:, 0, :] == ord("W")).all())
+    xs = torch.nonzero(lay == ord("X"))
+    assert len(torch.unique(xs[:, 1] * G + xs[:, 2])) > 800          # spread over the interior, not one pinned cell
     env = PKG.LmazeVecEnv(N, variant="v0", per_env_layouts=lay, seed=2)
+    assert not bool((lay.view(N, -1).gather(1, (env.ball_xy[:, 0] * G + env.ball_xy[:, 1]).long()[:, None]) != ord("B")).any())
     lay_np = _np(lay)
     st = {k: np.array(v, copy=True) for k, v in env.host_state().items()}
     # reset parity at full size (same Philox draws; per-env accepted-cell scan)

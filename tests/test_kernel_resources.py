@@ -22,9 +22,15 @@ HOT = {   # mangled-name fragment -> minimum waves per SIMD
     "step_perenv_wave_kernelILi32ELi0ELb1ELb1E": 6,        # C5
     "foveal_kernelILi1ELi0ELi32ELi14ELb0E": 6,             # v1 step
     "foveal_kernelILi2ELi0ELi128ELi18ELb0E": 6,            # v2 step
-    "foveal_kernelILi4ELi0ELi32ELi18ELb0E": 6,             # v4 step
-    "foveal_kernelILi4ELi0ELi64ELi18ELb1E": 6,             # v4 step with the reset fused in
-    "foveal_kernelILi5ELi0ELi64ELi18ELb1E": 5,             # v5/v6 two-level step (reset + plannerStep + step)
+    # v4-v6 since round 3 (clock-relative visit map, one lane per window row): a chunk's tile rows are held in registers
+    # across one barrier -- 27-45 VGPRs -- so that every load is in flight at once; measured at 1M envs, v4 303-320 us at
+    # 4 waves per SIMD against 363-376 for the variants that kept 5-6.  The floor guards against a slip
+    # below that.
+    "foveal_kernelILi4ELi0ELi128ELi18ELb0E": 4,            # v4 step (library default: 128 envs per workgroup)
+    "foveal_kernelILi4ELi0ELi64ELi18ELb0E": 4,
+    "foveal_kernelILi4ELi0ELi64ELi18ELb1E": 4,             # v4 step with the reset fused in
+    "foveal_kernelILi5ELi0ELi128ELi18ELb1E": 4,            # v5/v6 two-level step (reset + plannerStep + step)
+    "foveal_kernelILi5ELi0ELi64ELi18ELb1E": 4,
     "render_expanded_stream_kernelILi11ELi7ELb1E": 8,
     "render_planes_stream_kernelILb1E": 8,
 }

@@ -99,6 +99,8 @@ def test_v5_two_level_step_is_reset_then_planner_step_then_step(n, seed, steps):
         O.v5_planner_step(p, layouts, goal, m_plan, b)
         O.v5_step(p, layouts, act, b)
         for f, _ in O.FovealBuffers._fields_:
+            if f == "visit_clock":        # the product's clock-relative map only; the oracle keeps the reference's dense plane
+                continue
             x, y = getattr(a, f), getattr(b, f)
             assert (np.ascontiguousarray(x).view(np.uint8) == np.ascontiguousarray(y).view(np.uint8)).all(), (f, t)
 
