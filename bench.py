@@ -492,6 +492,14 @@ def main():
             per_rank = pkg.gather_over_ranks(my_elapsed, device=dev)
     # per-launch GPU time from HIP events recorded on the launch stream
     kern_ms = float(ev0.elapsed_time(ev1) / args.steps)   # ms per launch, launch gaps included
+    # every rank's own figures (a straggler in a multi-GPU run should explain itself): event time per launch, launch
+    # policy in force, where its observation buffer ended up
+    rank_kern_ms = pkg.gather_over_ranks(kern_ms, device=dev) if dist is not None else [kern_ms]
+    rank_hint = pkg.gather_over_ranks(float(int(env.params.launch_hint)), device=dev) if dist is not None else [float(int(env.params.launch_hint))]
+    rank_first_ms = None
+    pl = getattr(env, "placement", None)
+    if pl:
+        rank_first_ms = pkg.gather_over_ranks(pl["trials_ms"][0], device=dev) if dist is not None else [pl["trials_ms"][0]]
 
     # sanity: the run really stepped (every env advanced warmup+steps times)
     if hier:       # local episodes restart at plannerStep: nobody is past the local step limit
@@ -611,10 +619,23 @@ def main():
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_source,
                          "kernel": kernel, "bytes_per_env_step": B, "kernel_ms_avg": kern_ms,
                          "achieved_events": achieved_events, "frac_events": achieved_events / HBM_PEAK_GBS,
+                         # what a caller who never tries placements of the observation buffer gets (library default
+                         # placement_trials = 0): the first allocation under the tuned policy, HIP events, from autotune()
+                         "frac_first_allocation": (N * B / (pl["first_ms_tuned"] * 1e-3) / 1e9 / HBM_PEAK_GBS
+                                                   if pl and pl.get("first_ms_tuned") else None),
+                         "frac_kept_allocation": (N * B / (pl["kept_ms_tuned"] * 1e-3) / 1e9 / HBM_PEAK_GBS
+                                                  if pl and pl.get("kept_ms_tuned") else None),
                          "clock": "achieved / frac: ms_per_step (perf_counter around the timed launches, max over ranks); "
                                   "achieved_events / frac_events / kernel_ms_avg: HIP events on rank 0's launch stream",
                          "measured_ceiling": ceiling},
         }
+        out["per_rank"] = {
+            "ms_per_step": [round(x / args.steps * 1e3, 6) for x in per_rank],
+            "kernel_ms_avg": [round(x, 6) for x in rank_kern_ms],
+            "launch_hint": [int(x) for x in rank_hint],
+            "roofline_frac": [round(N * B / (x / args.steps) / 1e9 / HBM_PEAK_GBS, 4) for x in per_rank],
+            "roofline_frac_events": [round(N * B / (x * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) for x in rank_kern_ms],
+            "note": "one entry per rank, rank order; roofline.frac above is the slowest rank's (ms_per_step = max over ranks)"}
         if hier:
             out["config"]["v5_events_in_timed_steps"] = v5_events
             out["config"]["local_done_rate"] = v5_events["local_dones"] / float(N * args.steps)

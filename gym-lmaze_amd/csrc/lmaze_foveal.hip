@@ -1257,9 +1257,17 @@ static hipError_t launch_foveal_mode(const FovealArgs& a0, hipStream_t s) {
             else if (a.p.variant == LMAZE_VARIANT_V2) a.p.launch_hint = 0x35;
             // round 3 (window-only visit map): v4 128 envs per workgroup 305.8 us, 64 envs 311.2 (x 2 chunks 321, at 5 per
             // CU 308.7), 32 envs 406; v5/v6 128 envs 446-449 (x 2 chunks 446), 64 envs 503-511
-            else if (a.p.variant == LMAZE_VARIANT_V4) a.p.launch_hint = 0x40;
+            // (profiles/r03/foveal_sweep_{a,b}.jsonl, two boxes: v4 128 envs x 2 chunks 296.0 / 297.9 us, x 1 304-307, 64 x 2
+            // 299.7 / 301.3; v5/v6 128 envs 422.0 / 434.7, x 2 chunks 438.7 / 453.0, 64 envs 503-511)
+            else if (a.p.variant == LMAZE_VARIANT_V4) a.p.launch_hint = 0x140;
             else a.p.launch_hint = 0x40;
         }
+    }
+    if (MODE == FM_STEP && a.p.launch_hint == 0 && a.auto_reset && (size_t)a.n * W25 * 4 * 4 > kFovealStreamBytes) {
+        // fused reset (v1, v2, v4; one measured size each, below), same sweeps: v1 at 5 workgroups per CU 74.0 / 74.0 us
+        // against 74.2 / 76.8 uncapped; v2 two chunks 97.3 / 99.2 against 102.9 / 100.2; v4 two chunks 402-406 against 426-430
+        if (a.p.variant == LMAZE_VARIANT_V1) a.p.launch_hint = 0x05;
+        else if (a.p.variant == LMAZE_VARIANT_V2 || a.p.variant == LMAZE_VARIANT_V4) a.p.launch_hint = 0x100;
     }
     if (MODE == FM_STEP) {
         hipError_t rc = hipSuccess;

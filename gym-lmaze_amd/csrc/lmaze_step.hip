@@ -21,7 +21,11 @@
 //   mask        (observe only) re-render just the envs a masked reset touched
 #include <cstdio>
 
+#include <cmath>
+#include <cstdlib>
+
 #include "lmaze_common.h"
+#include "lmaze_policy_table.h"
 
 namespace lmaze {
 
@@ -184,7 +188,9 @@ __global__ __launch_bounds__(LMAZE_BLOCK) void step_shared_kernel(const StepArgs
     // DESIGN 5.3 describes).  With the fused reset the set-up is longer and staggers by itself: 78.5-83 us without
     // the wait against 84-86 with it.  (Found when the done flag's `auto_reset ? byte : 0` select -- a use of a loaded
     // value inside the branch above -- turned out to have been that wait all along.)
-    if (DO_STEP && NT && !autoreset) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    // It is a STAGGER, nothing else, and it is kept only while it pays: launch_hint bit 9 switches it off, and the guard
+    // test times both (tests/test_gpu_policy_guard.py).
+    if (DO_STEP && NT && !autoreset && !(a.launch_hint & 0x200)) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 
     // Large batches (NT): the first 256 workgroups touch every 64-byte line of this step's action row at kernel
     // start -- ONE burst of reads before the write stream saturates -- so that the chunk loads later in the
@@ -784,54 +790,50 @@ static size_t lds_for_workgroups_per_cu(int k) {
 // plain stores the cap hurts).  The optimum is narrow and shifts with shape and device, so the
 // caller can override it: LmazeParams.launch_hint bits 0-3 = workgroups per CU (0 = this
 // default), which LmazeVecEnv.autotune() picks by timing real steps.
+// ---- the default launch policy of the streaming regime is DATA: lmaze_policy_table.h, generated by tools/gen_policy.py
+// from sweeps recorded on MI355X boxes (profiles/rNN/shape_sweep_*.jsonl), looked up by grid side, rules, fused reset and
+// the nearest batch size in log2.  sel = the envs-per-workgroup selector of launch_hint bits 10-11 (0: the table's default
+// one).  tests/test_gpu_policy_guard.py checks the table's choice against a small sweep on the box it runs on.
+static bool specialised_grid(int g) { return g == 8 || g == 11 || g == 12 || g == 14 || g == 18 || g == 32; }
+
+static const StepPolicyRow* step_policy_lookup(int g, int variant, bool auto_reset, int64_t n, int sel) {
+    const StepPolicyRow* best = nullptr;
+    long best_cost = 0;
+    const int l2 = (int)lround(log2((double)(n < 1 ? 1 : n)) * 16.0);
+    for (int i = 0; i < kStepPolicyRows; ++i) {
+        const StepPolicyRow& r = kStepPolicy[i];
+        if ((r.auto_reset != 0) != auto_reset) continue;
+        if (sel == 0 ? !r.is_default : r.sel != sel) continue;
+        if (specialised_grid(g) != specialised_grid(r.g)) continue;
+        if (specialised_grid(g) && r.g != g) continue;
+        // lexicographic: grid distance (unspecialised G only), then rules, then batch size
+        const long cost = (long)abs(r.g - g) * 1000000 + (r.variant != variant ? 100000 : 0) + abs(r.log2n_x16 - l2);
+        if (!best || cost < best_cost) { best = &r; best_cost = cost; }
+    }
+    return best;
+}
+
+// the selector (launch_hint bits 10-11) that names EPB envs per workgroup for this grid size; see launch_one
+template <int GT, int EPB>
+constexpr int sel_of() {
+    if (GT == 11 || GT == 12) return EPB == 64 ? 1 : (EPB == 32 ? 2 : 3);
+    if (GT == 14 || GT == 18) return EPB == 32 ? 1 : 2;
+    if (GT == 8) return EPB == 128 ? 1 : 2;
+    if (GT == 32) return EPB == 8 ? 1 : 2;
+    return EPB == 256 ? 1 : (EPB == 64 ? 2 : 3);
+}
+
 template <int GT, int VARIANT, bool DO_STEP, int EPB>
 static hipError_t launch_shared(const StepArgs& a, hipStream_t s) {
     const int64_t blocks = (a.n + EPB - 1) / EPB;
     size_t lds = shared_lds_bytes(a.grid, GT != 0, EPB, VARIANT == LMAZE_VARIANT_V3);
     const bool nt = a.obs != nullptr && (size_t)a.n * a.grid * a.grid * 4 > kNonTemporalObsBytes;
-    // Defaults of the streaming regime, per shape, re-measured in round 2 after the set-up went to one global round trip
-    // (tools/policy_by_shape.py, three separately allocated batches per shape, all on a placement where only one or two
-    // policies run fast -- the robust case; us per step, best / the old default (3, 2)):
-    //   v0 11x11 1M   (3,1) 80.6-81.7 / 97-98     with the fused reset (3,2) 83.1-83.2 / the same
-    //   v0 8x8 2M     (2,1) 92.5-92.8 / 104-105   fused (2,1) 95.8-96.7 / 105
-    //   v0 12x12 1M   (2,1) 105-107 / 117-118     fused (2,1) 104.5-104.7 / 116-117
-    //   v3 18x18 512K (2,1) 110.4-110.9 / 130-131 fused (2,2) 111.7-111.9 / 130-131
-    //   v0 32x32 128K (2,1) 92.3-92.7 / 100-101   fused (3,2) 100-102 (2,1: 142)
-    //   v3 11x11 1M   (8,1) 91.3-91.6 / 107       fused (8,1) 97.4-97.7 / 117
-    // (On a placement where everything runs fast, v0 11x11 (3,2) and (4,2) reach 76-80 us; LmazeVecEnv.autotune()
-    // finds that out.)  Since then v0 11x11 runs 32 envs per workgroup, uncapped, one chunk (launch_one): 76.1-78.9 us,
-    // with the fused reset 78.8-84.6; the 64-env rows above are what launch_hint bits 10-11 = 1 selects.
-    // launch_hint bits 0-3 / 4-7 override workgroups per CU / chunks per workgroup.
+    // default (workgroups per CU, chunks per workgroup) of the streaming regime: the generated table (round 2 kept them
+    // in a hand-edited if-chain here, retuned four times in its last hour; LAB_NOTES.md has that history)
     int def_cu = 3, def_m = 2;
-    if (GT == 0) {
-        // profiles/r02/shape_sweep.jsonl (G = 9, 10, 13, 16, 20, 24, 27): 16 envs (5, 2) beats (5, 1) by 2-9 %, with the
-        // fused reset (8, 2) by 3-22 %; 64 envs below G = 12: (5, 1), fused reset (5, 2)
-        if (EPB == 16) { def_cu = a.auto_reset ? 8 : 5; def_m = 2; }
-        else if (EPB == 64 && a.grid < 12) { def_cu = 5; def_m = a.auto_reset ? 2 : 1; }
-    } else if (GT == 11) {
-        // 32 envs: uncapped up to about 1.5M envs; from 2M on a cap pays (2M / 3M / 4M / 8M envs, us per step: (5, 1) 162 /
-        // 243 / 321 / 681 against 171 / 262 / 370 / 719 uncapped; 1.5M: 117 against 112)
-        if (EPB == 32) { def_cu = a.n >= ((int64_t)1 << 21) ? 5 : 8; def_m = 1; }
-        else if (VARIANT == LMAZE_VARIANT_V3) { def_cu = 8; def_m = 1; }
-        else if (a.auto_reset) { def_cu = 3; def_m = 2; }
-        else { def_cu = 3; def_m = 1; }
-    } else if (GT == 32 && EPB == 4) {
-        def_cu = a.auto_reset ? 6 : 5; def_m = 1;
-    } else if (GT == 8 && EPB == 64) {
-        def_cu = 4; def_m = 1;
-    } else if (GT == 14 && EPB == 16) {
-        def_cu = 5; def_m = VARIANT == LMAZE_VARIANT_V3 ? 2 : 1;     // v3 (bit-string render): (5, 2) 127 us, (5, 1) 150
-    } else if (GT == 12 && EPB == 16) {
-        def_cu = 8; def_m = 1;
-        if (a.auto_reset) { def_cu = 5; def_m = 2; }               // fused reset: (5, 2) 92.7-93.8 us on three boxes, (8, 1) 103-107
-    } else if (GT == 8 || GT == 12 || GT == 14) {
-        def_cu = 2; def_m = 1;
-    } else if (GT == 18 && EPB == 16) {
-        def_cu = a.auto_reset ? 6 : 5; def_m = 1;                   // fused reset: 6-8 per CU 102.5-104 us on three boxes, 5 per CU 107-109
-    } else if (GT == 18) {
-        def_cu = 2; def_m = a.auto_reset ? 2 : 1;
-    } else if (GT == 32) {
-        if (!a.auto_reset) { def_cu = 2; def_m = 1; }
+    if (const StepPolicyRow* r = step_policy_lookup(a.grid, VARIANT, a.auto_reset != 0, a.n, sel_of<GT, EPB>())) {
+        def_cu = r->per_cu;
+        def_m = r->chunks;
     }
     int per_cu = a.launch_hint & 15;
     if (per_cu == 0 && nt) per_cu = def_cu;
@@ -912,6 +914,13 @@ static hipError_t launch_perenv(const StepArgs& a, hipStream_t s) {
     return hipGetLastError();
 }
 
+// the table's default envs-per-workgroup selector for this launch (streaming regime), or `fallback`
+template <int VARIANT>
+static int table_sel(const StepArgs& a, int fallback) {
+    const StepPolicyRow* r = step_policy_lookup(a.grid, VARIANT, a.auto_reset != 0, a.n, 0);
+    return r ? r->sel : fallback;
+}
+
 // Envs per workgroup for the shared-layout kernel: about 32 KiB of observation per workgroup
 // (8 sixteen-byte stores per lane).  Measured at G=11 on MI355X (tools/kbench.hip): 64 envs
 // (31 KiB) 90-91 us per 1M-env step, 128/256 envs 96-101 us, 32 envs 120 us.
@@ -950,7 +959,7 @@ static hipError_t launch_one(const StepArgs& a, int layout_mode, hipStream_t s) 
         // large 8x8 batches: launch_hint bits 10-11: 1: 128 envs per workgroup, 2: 64 (16 KiB of planes).  2M envs: 64 envs at
         // 4 / 5 / 6 / 8 per CU 89.0 / 91.7 / 91.8 / 91.7 us, 128 envs at (2, 1) 92.6, at 3-8 per CU 102-105.
         int sel = (a.launch_hint >> 10) & 3;
-        if (sel == 0) sel = a.obs != nullptr ? 2 : 1;
+        if (sel == 0) sel = table_sel<VARIANT>(a, a.obs != nullptr ? 2 : 1);
         if (sel == 2) return launch_shared<GT, VARIANT, DO_STEP, 64>(a, s);
         return launch_shared<GT, VARIANT, DO_STEP, 128>(a, s);
     } else if constexpr (GT == 11 || GT == 12) {
@@ -966,6 +975,7 @@ static hipError_t launch_one(const StepArgs& a, int layout_mode, hipStream_t s) 
         if (sel == 0) {
             if (GT == 11) sel = streaming ? 2 : 1;      // the render-only launches (lmaze_observe) write the same stream
             else sel = streaming ? 3 : 1;
+            if (streaming) sel = table_sel<VARIANT>(a, sel);
         }
         if (sel == 2) return launch_shared<GT, VARIANT, DO_STEP, 32>(a, s);
         if (sel == 3) return launch_shared<GT, VARIANT, DO_STEP, 16>(a, s);
@@ -977,7 +987,8 @@ static hipError_t launch_one(const StepArgs& a, int layout_mode, hipStream_t s) 
         // for 32 at (2, 1) -- but 118-134 one step to either side, so there it stays a tuner candidate.
         int sel = (a.launch_hint >> 10) & 3;
         const bool streaming = a.obs != nullptr && (size_t)a.n * GT * GT * 4 > kNonTemporalObsBytes;
-        if (sel == 0) sel = ((GT == 14 || VARIANT == LMAZE_VARIANT_V3) && streaming) ? 2 : 1;   // v3 18x18 since its render went to bit strings: 16 envs at 4-5 per CU 109 us (with the fused reset 5-8 per CU 103-107) against 112-120
+        if (sel == 0) sel = ((GT == 14 || VARIANT == LMAZE_VARIANT_V3) && streaming) ? 2 : 1;
+        if (((a.launch_hint >> 10) & 3) == 0 && streaming) sel = table_sel<VARIANT>(a, sel);   // v3 18x18 since its render went to bit strings: 16 envs at 4-5 per CU 109 us (with the fused reset 5-8 per CU 103-107) against 112-120
         if (sel == 2) return launch_shared<GT, VARIANT, DO_STEP, 16>(a, s);
         return launch_shared<GT, VARIANT, DO_STEP, 32>(a, s);
     } else if constexpr (GT == 32) {
@@ -986,14 +997,17 @@ static hipError_t launch_one(const StepArgs& a, int layout_mode, hipStream_t s) 
         // reset 4 envs at (5, 1) 88.6 / 342, at (6, 1) 81.8 / 313, against 102 / 403.
         int sel = (a.launch_hint >> 10) & 3;
         const bool streaming = a.obs != nullptr && (size_t)a.n * GT * GT * 4 > kNonTemporalObsBytes;
-        if (sel == 0) sel = streaming ? 2 : 1;
+        if (sel == 0) sel = streaming ? table_sel<VARIANT>(a, 2) : 1;
         if (sel == 2) return launch_shared<GT, VARIANT, DO_STEP, 4>(a, s);
         return launch_shared<GT, VARIANT, DO_STEP, 8>(a, s);
     } else {  // unspecialised G: three sizes cover [3, 64]; launch_hint bits 10-11: 1: 256, 2: 64, 3: 16 envs per workgroup
         // Round 2 (1M envs at G = 9, 10, 13; 512K at 16, 20; 256K at 27; us per step, old -> new default): 64.9 -> 56.4,
         // 88.0 -> 76.2, 120.7 (unchanged), 118.9 -> 90.0 (16 envs at (5, 2): 81.7), 169.7 -> 148.1, 155.3 -> 152.
         int sel = (a.launch_hint >> 10) & 3;
-        if (sel == 0) sel = a.grid >= 15 ? 3 : (a.grid >= 5 ? 2 : 1);
+        if (sel == 0) {
+            sel = a.grid >= 15 ? 3 : (a.grid >= 5 ? 2 : 1);
+            if (a.obs != nullptr && (size_t)a.n * a.grid * a.grid * 4 > kNonTemporalObsBytes && a.grid >= 5) sel = table_sel<VARIANT>(a, sel);
+        }
         if (sel == 3) return launch_shared<GT, VARIANT, DO_STEP, 16>(a, s);
         if (sel == 2) return launch_shared<GT, VARIANT, DO_STEP, 64>(a, s);
         return launch_shared<GT, VARIANT, DO_STEP, 256>(a, s);

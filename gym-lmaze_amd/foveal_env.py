@@ -311,6 +311,7 @@ class LmazeFovealVecEnv(object):
             with torch.cuda.graph(graph, stream=side):
                 self.rollout(actions, goals=goals, auto_reset=auto_reset, device_epoch=needs_epoch)
         torch.cuda.current_stream(self.device).wait_stream(side)
+        self._captured = getattr(self, "_captured", 0) + 1
         return RolloutGraph(self, graph, int(actions.shape[0]), needs_epoch)
 
     # launch policies autotune() tries: LmazeFovealParams.launch_hint = ((chunks per workgroup - 1) << 8) |
@@ -337,6 +338,9 @@ class LmazeFovealVecEnv(object):
         if self._two_level and goals is None:
             raise ValueError("v5/v6: autotune() times the two-level step and needs planner goals")
         cands = list(candidates or self.CANDIDATES)
+        if int(placement_trials) > 1 and getattr(self, "_captured", 0):
+            raise RuntimeError("autotune(placement_trials > 1) would move the observation buffer under %d captured rollout(s): "
+                               "tune before capture_rollout()" % self._captured)
         R = int(actions.shape[0])
         snap = self.snapshot()
         obs_snap = (self.obs.clone(), None if self.obs_local is None else self.obs_local.clone())
@@ -369,7 +373,9 @@ class LmazeFovealVecEnv(object):
                     ms_of.append(e0.elapsed_time(e1) / 12)
                 keep = min(range(len(bufs)), key=lambda i: ms_of[i])
                 self.placement = {"trials_ms": [round(m, 5) for m in ms_of], "kept": keep}
-                self.obs = bufs[keep]
+                first_alloc = self.obs.view_as(self.obs) if keep != 0 else None    # keeps the first allocation alive (timed below)
+                if keep != 0:
+                    self.obs.set_(bufs[keep])      # the same tensor object on the winning allocation: held references stay valid
                 self.bufs.obs = self.obs.data_ptr()
                 self._expanded = None
                 del bufs
@@ -384,6 +390,26 @@ class LmazeFovealVecEnv(object):
                     e1.synchronize()
                     ms = e0.elapsed_time(e1) / steps
                     timings.setdefault(h, []).append(ms)
+            if int(placement_trials) > 1:
+                # what a caller who never tries placements gets: the FIRST allocation under the policy about to be chosen
+                med = {h: sorted(v)[len(v) // 2] for h, v in timings.items()}
+                b0 = min(med, key=med.get)
+                if 0 in med and med[b0] > 0.985 * med[0]:
+                    b0 = 0
+                self.params.launch_hint = int(b0)
+                kept_ptr = self.bufs.obs
+                for name, ptr in (("kept_ms_tuned", kept_ptr),
+                                  ("first_ms_tuned", first_alloc.data_ptr() if first_alloc is not None else kept_ptr)):
+                    self.bufs.obs = ptr
+                    run(3)
+                    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    e0.record()
+                    run(steps)
+                    e1.record()
+                    e1.synchronize()
+                    self.placement[name] = round(e0.elapsed_time(e1) / steps, 5)
+                self.bufs.obs = kept_ptr
+                first_alloc = None
             self.restore(snap)
             # the observations too: the tuning steps rendered into them, and with placement trials
             # self.obs may be another allocation by now -- the caller must see the frame of the restored state

@@ -181,6 +181,39 @@ class LmazeEnv_v1(_FovealBase):
     def getLocalView(self):                                  # v1:242-279 (what step()/setFovealGoal() return)
         return self._out()
 
+    def getGlobalView(self):
+        """v1:204-238: the 5x5 window around the ball of [ball, 'W', 'X', free] -- the global goal where getLocalView()
+        shows the foveal goal --, x7; what reset() returns (v1:100).  Changes nothing but the returned buffer: rendered
+        by the reset-mode launch of lmaze_foveal_reset (place = 0 keeps the ball) with the per-env scalars put back."""
+        core = self._core
+        snap = core._state.clone()
+        core.reset(place=False)
+        core._epoch -= 1                                     # no placement was drawn
+        core._state.copy_(snap)
+        self._host = None
+        return self._out()
+
+    @property
+    def state(self):
+        """v1:66-80 + the ball cell step() moves (v1:142-147): float32[4*G*G] -- ball one-hot, 'W', 'X', free = B|S|X --
+        of the single env; float32[N, 4*G*G] (a torch tensor on the device) for a batch."""
+        G = self.realgrid
+        g = np.asarray(self.grid)
+        static = np.stack([np.zeros((G, G)), g == 'W', g == 'X', np.isin(g, ['B', 'S', 'X'])]).astype(np.float32)
+        if self._single:
+            out = static.copy()
+            out[0, self.ball_x0, self.ball_y0] = 1.0
+            return out.reshape(-1)
+        import torch
+        core = self._core
+        out = torch.from_numpy(static.reshape(-1)).to(core.device).repeat(self.num_envs, 1)
+        idx = (core.ball_xy[:, 0] * G + core.ball_xy[:, 1]).long()
+        out[torch.arange(self.num_envs, device=core.device), idx] = 1.0
+        return out
+
+    def initState(self):                                     # v1:289-290
+        return self.state, self.originalReward, self.isEpisodeFinished(), {'newState': True}
+
     def isEpisodeFinished(self, queryType="plain"):          # v1:294-304
         if self._single:
             return bool(self.originalReward == self.positiveFull or self.stepCount == 200)

@@ -59,8 +59,10 @@ class LmazeVecEnv(object):
                       one (keys the reset draws; see include/lmaze.h lmaze_reset)
     online_autotune   OPT-IN (default False: the library's default launch policy, nothing timed).  True, on
                       large shared-layout batches only (the streaming regime): time the launch policies on
-                      the caller's own first ~250 steps, in the caller's own loop -- those steps cycle through 12
-                      policies, each bracketed by an event pair, up to 20 % slower -- and keep the fastest
+                      the caller's own first ~200 steps, in the caller's own loop -- after 100 untimed steps they cycle
+                      through the 8 policies of ONLINE_CANDIDATES, 12 samples each, each launch bracketed by an event
+                      pair; a step under a losing policy can take up to twice as long (76 against 152 us for (2, 1) at
+                      1M x 11x11) -- and keep the fastest, the library default unless another beats it by more than 1.5 %
                       (see OnlineTuner; `tuning_progress()` reports where it is, `tuned_policy` the winner; one
                       log line when it starts and one when it ends); autotune() or set_launch_policy() switch it off.
                       Results never depend on the policy.
@@ -141,10 +143,10 @@ class LmazeVecEnv(object):
         self._cmask = (C.c_int32 * len(self.channel_mask))(*self.channel_mask)
         self._bind_pointers()
         streaming = self.layout_mode == _abi.LAYOUT_SHARED and N * G * G * 4 > (192 << 20)
-        self._tuner = OnlineTuner(self.CANDIDATES) if (online_autotune and streaming) else None
+        self._tuner = OnlineTuner(self.ONLINE_CANDIDATES) if (online_autotune and streaming) else None
         if self._tuner is not None:
             _log.info("gym-lmaze_amd: online launch-policy tuning on for the next ~%d steps of this %d-env batch",
-                      self._tuner.warm + self._tuner.samples * len(self.CANDIDATES), N)
+                      self._tuner.warm + self._tuner.samples * len(self.ONLINE_CANDIDATES), N)
 
         if not self._is_v3:
             # v0 looks the goal up once from the layout (lmaze_env.py:100-102): first 'X', row-major
@@ -235,7 +237,10 @@ class LmazeVecEnv(object):
         return sum(len(v) for v in t.timings.values()), t.samples * len(t.candidates)
 
     def set_launch_policy(self, per_cu, chunks=1):
-        """Fix the launch policy (workgroups per CU, chunks per workgroup) and stop any tuning."""
+        """Fix the launch policy (workgroups per CU, chunks per workgroup) and stop any tuning.  On-die 8x8 batches (up
+        to 192 MiB of planes, shared layout) run the wave-autonomous kernel, which reads the same two fields as waves
+        per workgroup (1, 2, 4) and envs per wave (1: 64, 2: 32, 3: 16) -- include/lmaze.h, launch_hint; a value
+        outside those sets means its default there.  `_abi.describe_step(env.params, N)` shows what a hint selects."""
         self.params.launch_hint = self.launch_hint_of(per_cu, chunks)
         self._tuner = None
 
@@ -290,11 +295,15 @@ class LmazeVecEnv(object):
     CANDIDATES = ((0, 0), (2, 1), (2, 2), (3, 1), (3, 2), (4, 1), (4, 2), (5, 2), (6, 2), (7, 2), (8, 1), (8, 2),
                   (6, 1, 2), (8, 1, 2), (5, 1, 2), (4, 2, 2), (3, 1, 2), (4, 1, 2), (3, 2, 2), (4, 1, 1), (3, 2, 1), (2, 1, 1), (2, 2, 1), (8, 1, 3), (5, 2, 3))
 
+    # the online tuner's own, shorter list (it runs inside the caller's loop): the default and the pairs that have won on
+    # some box for some shape (profiles/r02/shape_sweep.jsonl)
+    ONLINE_CANDIDATES = ((0, 0), (3, 1), (3, 2), (5, 2), (8, 1), (6, 1, 2), (8, 2, 2), (5, 2, 2))
+
     @staticmethod
-    def launch_hint_of(per_cu, chunks=1, epb_sel=0):
+    def launch_hint_of(per_cu, chunks=1, epb_sel=0, no_stagger=False):
         """LmazeParams.launch_hint for `per_cu` workgroups per CU, `chunks` chunks per workgroup and, where the kernel
-        offers the choice, the envs-per-workgroup selector (include/lmaze.h: bits 10-11)."""
-        return (int(per_cu) & 15) | ((int(chunks) & 15) << 4) | ((int(epb_sel) & 3) << 10)
+        offers the choice, the envs-per-workgroup selector (include/lmaze.h: bits 10-11); no_stagger: bit 9."""
+        return (int(per_cu) & 15) | ((int(chunks) & 15) << 4) | ((int(epb_sel) & 3) << 10) | (0x200 if no_stagger else 0)
 
     def autotune(self, auto_reset=False, actions=None, steps=24, candidates=None, warm=150, between=None, rounds=3,
                  placement_trials=0):
@@ -337,6 +346,9 @@ class LmazeVecEnv(object):
                   and actions.shape[1] == N and actions.device == self.device and actions.is_contiguous()):
             raise ValueError("autotune(actions=...) wants a contiguous int32[T,N] tensor on %s" % (self.device,))
         base, stride, R = actions.data_ptr(), N * 4, int(actions.shape[0])
+        if int(placement_trials) > 1 and getattr(self, "_captured", 0):
+            raise RuntimeError("autotune(placement_trials > 1) would move the observation buffer under %d captured rollout(s), "
+                               "which keep raw pointers to it: tune before capture_rollout()" % self._captured)
         snap, epoch = self._state.clone(), self._epoch
         self._tuner = None                   # an explicit autotune replaces the online one
         timings, t = {}, 0
@@ -363,7 +375,11 @@ class LmazeVecEnv(object):
                     ms_of.append(e0.elapsed_time(e1) / 12)
                 keep = min(range(len(bufs)), key=lambda i: ms_of[i])
                 self.placement = {"trials_ms": [round(m, 5) for m in ms_of], "kept": keep}
-                self.obs = bufs[keep]
+                first_alloc = self.obs.view_as(self.obs) if keep != 0 else None    # keeps the first allocation alive (timed below)
+                if keep != 0:
+                    # the SAME tensor object takes over the winning allocation: references the caller already holds to
+                    # env.obs stay valid; the first allocation is freed with the rest
+                    self.obs.set_(bufs[keep])
                 self._p_obs = self.obs.data_ptr()
                 self._expanded = None
                 del bufs
@@ -395,9 +411,32 @@ class LmazeVecEnv(object):
                         d = sorted(x.elapsed_time(y) for x, y in pairs)
                         ms = d[len(d) // 2]
                     timings.setdefault(c, []).append(ms)
+            timings = {c: sorted(v)[len(v) // 2] for c, v in timings.items()}
+            best = min(timings, key=timings.get)
+            if self.DEFAULT_POLICY in timings and timings[best] > 0.985 * timings[self.DEFAULT_POLICY]:
+                best = self.DEFAULT_POLICY
+            if int(placement_trials) > 1:
+                # what a caller who never tries placements gets: the FIRST allocation under the policy just chosen, timed
+                # beside the kept one (bench.py prints both roofline fractions)
+                self.params.launch_hint = self.launch_hint_of(*best)
+                pair = {}
+                for name, ptr in (("kept_ms_tuned", self._p_obs),
+                                  ("first_ms_tuned", first_alloc.data_ptr() if first_alloc is not None else self._p_obs)):
+                    for _ in range(3):
+                        self._launch_step(base + (t % R) * stride, ptr, auto_reset)
+                        t += 1
+                    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    e0.record()
+                    for _ in range(steps):
+                        self._launch_step(base + (t % R) * stride, ptr, auto_reset)
+                        t += 1
+                    e1.record()
+                    e1.synchronize()
+                    pair[name] = round(e0.elapsed_time(e1) / steps, 5)
+                self.placement.update(pair)
+                first_alloc = None
             self._state.copy_(snap)
             self._epoch = epoch
-        timings = {c: sorted(v)[len(v) // 2] for c, v in timings.items()}
         best = min(timings, key=timings.get)
         if self.DEFAULT_POLICY in timings and timings[best] > 0.985 * timings[self.DEFAULT_POLICY]:
             best = self.DEFAULT_POLICY
@@ -492,6 +531,7 @@ class LmazeVecEnv(object):
             with torch.cuda.graph(graph, stream=side):
                 self.rollout(actions, auto_reset=auto_reset, device_epoch=auto_reset)
         torch.cuda.current_stream(self.device).wait_stream(side)
+        self._captured = getattr(self, "_captured", 0) + 1      # the graph keeps raw pointers: autotune() no longer moves obs
         return RolloutGraph(self, graph, T, auto_reset)
 
     def episode_stats(self, all_ranks=False):
@@ -565,7 +605,11 @@ class OnlineTuner:
             self.timings[c].append(a.elapsed_time(b))
         if all(len(v) >= self.samples for v in self.timings.values()):
             med = {c: sorted(v)[len(v) // 2] for c, v in self.timings.items()}
-            return min(med, key=med.get)
+            best = min(med, key=med.get)
+            # as autotune(): the library default stays unless another policy beats it by more than 1.5 %
+            if (0, 0) in med and med[best] > 0.985 * med[(0, 0)]:
+                best = (0, 0)
+            return best
         return None
 
 

@@ -88,6 +88,9 @@ typedef struct LmazeParams {
                                          on-die); for the wave-autonomous kernel bits 4-7 = envs per
                                          wave (1: 64, 2: 32, 3: 16), bits 0-3 = waves per workgroup
                                          (1, 2, 4)
+                              bit  9     streaming regime without the fused reset: drop the early wait on the
+                                         per-env loads that staggers the workgroups of a CU (a measured +8-15 %
+                                         at 1M x 11x11; the launch-policy guard test times both)
                               bits 10-11 envs per workgroup (0 = default):
                                            11x11, 12x12        1: 64   2: 32   3: 16
                                            14x14, 18x18        1: 32   2: 16

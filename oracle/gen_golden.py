@@ -391,7 +391,8 @@ def rollout_v1(actions, fgoals, seed, reset_on_done=True):
                ball=np.zeros((T, 2), np.int32), step_count=np.zeros(T, np.int32),
                foveal_step_count=np.zeros(T, np.int32),
                planes=np.zeros((T, 4, 5, 5), np.float32), obs_hash=np.zeros(T, np.uint64),
-               setgoal_planes=np.zeros((T, 4, 5, 5), np.float32))
+               setgoal_planes=np.zeros((T, 4, 5, 5), np.float32),
+               global_planes=np.zeros((T, 4, 5, 5), np.float32), state_hash=np.zeros(T, np.uint64))
     reset_planes, reset_hash = [], []
     need_reset, need_goal = True, True
     k = 0
@@ -425,6 +426,12 @@ def rollout_v1(actions, fgoals, seed, reset_on_done=True):
         rec["foveal_step_count"][t] = env.fovealStepCount
         rec["planes"][t] = unexpand(o, E)
         rec["obs_hash"][t] = obs_hash(o)
+        # the two extras a caller can ask for between steps (lmaze_env_v1.py:204-238, 289-290); neither changes the env
+        gv = env.getGlobalView()
+        rec["global_planes"][t] = unexpand(gv, E)
+        st4, r0, d0, info0 = env.initState()
+        assert st4 is env.state and r0 == env.originalReward and d0 == d and info0 == {'newState': True}
+        rec["state_hash"][t] = obs_hash(np.ascontiguousarray(st4, dtype=np.float32))
         if d and reset_on_done:
             need_reset = True
         elif fd:

@@ -113,6 +113,11 @@ def test_plain_gpus_2_launches_its_own_ranks():
     assert "self" in d["config"]["launcher"] and "REHEARSAL" in d["config"]["collective_backend"]
     pr = d["per_rank_ms_per_step"]
     assert len(pr["all"]) == 2 and pr["min"] <= pr["max"] and abs(pr["max"] - d["ms_per_step"]) < 1e-9
+    # the N > 1 line explains its own stragglers: every rank's event time, launch policy and roofline fraction
+    q = d["per_rank"]
+    assert all(len(q[k]) == 2 for k in ("ms_per_step", "kernel_ms_avg", "launch_hint", "roofline_frac", "roofline_frac_events"))
+    assert abs(min(q["roofline_frac"]) - d["roofline"]["frac"]) <= 2e-4 and all(0 < f < 1 for f in q["roofline_frac_events"])
+    assert all(k > 0 for k in q["kernel_ms_avg"]) and all(isinstance(h, int) for h in q["launch_hint"])
     assert abs(d["value"] - d["config"]["global_envs"] * d["steps"] / (d["ms_per_step"] * 1e-3 * d["steps"])) <= 1e-6 * d["value"]
     assert "cpu_baseline" not in d
 

@@ -263,6 +263,44 @@ def test_dropin_v1_six_tuple():
     assert (env.goal_x, env.goal_y) == tuple(g["goal"])
 
 
+@pytest.mark.parametrize("name", ["v1_seed1", "v1_scripted_goal"])
+def test_dropin_v1_global_view_and_init_state(name):
+    """LmazeEnv_v1.getGlobalView() (lmaze_env_v1.py:204-238) and .initState() (:289-290) after every step of a reference
+    rollout: the window with the GLOBAL goal plane, the 4-tuple with the flat [ball, 'W', 'X', free] state -- and neither
+    moves the env (the following steps still match the recording)."""
+    import gym_lmaze
+    g = load_golden(name)
+    E = int(g["E"])
+    env = gym_lmaze.make("lmaze-v1")
+    for t in range(min(len(g["actions"]), 160)):
+        if g["reset_before"][t]:
+            env.reset()
+        if g["setgoal_before"][t]:
+            env.setFovealGoal(*[int(v) for v in g["setgoal_ij"][t]])
+        o, r, fr, fd, d, _ = env.step(int(g["actions"][t]))
+        assert obs_hash(o) == g["obs_hash"][t], t
+        gv = env.getGlobalView()
+        assert gv.shape == (4, 35, 35) and gv.dtype == np.float32
+        assert (_bits(gv[:, ::E, ::E]) == _bits(g["global_planes"][t])).all(), t
+        assert (gv == np.repeat(np.repeat(gv[:, ::E, ::E], E, 1), E, 2)).all()
+        st, r0, d0, info = env.initState()
+        assert isinstance(st, np.ndarray) and st.dtype == np.float32 and st.shape == (4 * 14 * 14,)
+        assert obs_hash(np.ascontiguousarray(st)) == g["state_hash"][t], t
+        assert r0 == g["reward"][t] and d0 == bool(g["done"][t]) and info == {'newState': True}
+        assert (env.ball_x0, env.ball_y0) == tuple(g["ball"][t]) and env.stepCount == g["step_count"][t]
+        assert env.fovealStepCount == g["foveal_step_count"][t] and env.fovealReward == g["foveal_reward"][t]
+    # batched: the same view for every env of a batch, state as a device tensor
+    b = PKG.LmazeEnv_v1(num_envs=33)
+    b.setFovealGoal(2, 3)
+    b.step(torch.full((33,), 3, dtype=torch.int32))
+    before = b._core._state.clone()
+    gv = b.getGlobalView()
+    assert tuple(gv.shape) == (33, 4, 5, 5) and bool((b._core._state == before).all())      # a batch returns the compact planes
+    assert float(gv[:, 0].sum()) == 33.0 and float(gv[:, 0, 2, 2].sum()) == 33.0             # the ball, at the window centre
+    st, r0, d0, info = b.initState()
+    assert tuple(st.shape) == (33, 4 * 14 * 14) and float(st[:, :196].sum()) == 33.0 and info == {'newState': True}
+
+
 # ---------------------------------------------------------------- v5 / v6 (two-level loop)
 def _check_v56(env, g, t):
     h = env.host_state()
@@ -655,6 +693,13 @@ def test_foveal_autotune_picks_a_hint_and_leaves_no_trace(variant):
     assert tuned.params.launch_hint == tuned.tuned_policy and tuned.tuned_policy in (best, 0)
     assert tuned.tuned_policy == best or ms[best] > 0.985 * ms[0]
     assert tuned._epoch == plain._epoch
+    # immediately after autotune(): the caller still sees the frame of the restored state (the tuning steps
+    # render into obs / obs_local, and with placement trials obs may be another allocation by now)
+    assert (_bits(_np(tuned.obs)) == _bits(_np(plain.obs))).all()
+    if tuned.obs_local is not None:
+        assert (_bits(_np(tuned.obs_local)) == _bits(_np(plain.obs_local))).all()
+    if tuned.visit is not None:
+        assert (_bits(_np(tuned.visit)) == _bits(_np(plain.visit))).all()
     for t in range(T):
         for e in (tuned, plain):
             if variant == "v5":
