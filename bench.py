@@ -292,6 +292,12 @@ def parse_args(argv=None):
     ap.add_argument("--placement-trials", type=int, default=10,
                     help="autotune: observation buffers tried (the fastest placement is kept, the others freed; 1 = keep "
                          "the first allocation)")
+    ap.add_argument("--obs-dtype", choices=["int32", "u8"], default="int32",
+                    help="grid workloads with a shared layout: u8 = the narrow observation (one byte per cell, lmaze_step_u8), a "
+                         "separate workload with its own algorithmic bytes 37 + G*G; int32 is the metric's mode")
+    ap.add_argument("--one-launch", action="store_true",
+                    help="c2: the K timed steps as ONE lmaze_rollout call (a wave keeps its envs in registers across the steps; "
+                         "launch-bound sizes) instead of K step launches")
     ap.add_argument("--graph", action="store_true",
                     help="capture the K timed launches into one hipGraph and time its replay (launch-bound sizes)")
     ap.add_argument("--action-rows", type=int, default=None,
@@ -427,10 +433,11 @@ def main():
             workload = ("%d x %dx%d mazes per GPU, v0 rules, per-env random layouts (border 'W', interior walls i.i.d. p 0.25, "
                         "Philox seed 7+rank, 'X' on a uniformly chosen free cell, ball on another), compact int32 obs" % (N, G, G))
         else:
-            env = pkg.LmazeVecEnv(N, variant="v0", layout=layout, device=dev, seed=1, env_base=env_base)
-            workload = "%d x %dx%d mazes per GPU, v0 rules, shared layout: %s, compact int32 obs" % (
+            env = pkg.LmazeVecEnv(N, variant="v0", layout=layout, device=dev, seed=1, env_base=env_base, obs_dtype=args.obs_dtype)
+            workload = "%d x %dx%d mazes per GPU, v0 rules, shared layout: %s, compact %s obs" % (
                 N, G, G, "the 8x8 literal of lmaze_env.py:28-35 with a 'W' border" if args.workload == "c2" and G == 8
-                else "open room with a 'W' border, 'S' at (1,1), 'X' at (%d,%d)" % (G // 2, G // 2))
+                else "open room with a 'W' border, 'S' at (1,1), 'X' at (%d,%d)" % (G // 2, G // 2),
+                "uint8 (NOT the metric's mode: 37 + G*G bytes per env-step)" if args.obs_dtype == "u8" else "int32")
 
         actions = torch.randint(0, 4, (R, N), dtype=torch.int32, device=dev, generator=gen)
         row_ptr = [actions[r].data_ptr() for r in range(R)]
@@ -462,6 +469,13 @@ def main():
         if dist is not None:
             dist.barrier()
         torch.cuda.synchronize()
+        roll_actions = None
+        if args.one_launch:
+            if foveal or args.graph:
+                raise SystemExit("--one-launch is lmaze_rollout of the grid workloads, without --graph")
+            roll_actions = actions[(torch.arange(args.warmup, args.warmup + args.steps, device=dev) % R)].contiguous()
+            env.rollout(roll_actions[:8].contiguous(), auto_reset=args.auto_reset)      # first call of the rollout kernel, untimed
+            torch.cuda.synchronize()
         # HIP events on the stream the kernels are launched on (torch's current stream)
         ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         t0 = time.perf_counter()
@@ -480,6 +494,9 @@ def main():
             if args.auto_reset:
                 env.begin_replay(args.steps)
             graph.replay()
+        elif args.one_launch:
+            # rows warmup .. warmup + steps - 1 of the ring, gathered into one contiguous int32[K, N] tensor beforehand
+            env.rollout(roll_actions, auto_reset=args.auto_reset)
         else:
             run(args.warmup, args.steps)
         ev1.record()
@@ -509,7 +526,7 @@ def main():
         top = int(env.step_count.max().item())
         assert top >= 1 and (not args.auto_reset or top <= env.params.step_limit + 1)
     elif not args.auto_reset:
-        assert int(env.step_count.min().item()) == args.warmup + args.steps
+        assert int(env.step_count.min().item()) == args.warmup + args.steps + (8 if args.one_launch else 0)
     else:  # episodes restart: nobody is past the step limit, and everybody moved
         assert 1 <= int(env.step_count.min().item()) and int(env.step_count.max().item()) <= env.step_limit
 
@@ -555,6 +572,8 @@ def main():
                                       + V4_RESET * v4_events["resets"]) / float(N * args.steps)
         else:
             B = FOVEAL_BYTES[args.workload] if foveal else bytes_per_env_step(G, args.per_env_layouts)
+            if args.obs_dtype == "u8" and not foveal:
+                B = 37 + G * G
         total_steps = world * N * args.steps
         value = total_steps / elapsed
         # ONE clock: achieved / frac follow from the line's own ms_per_step (host wall time around the timed launches,
@@ -584,7 +603,10 @@ def main():
             kernel = "lmaze::" + abi.describe_foveal_step(env.params, N, auto_reset=bool(args.auto_reset) or hier)
             perenv_kernel = None
         else:
-            kernel = "lmaze::" + abi.describe_step(env.params, N, auto_reset=bool(args.auto_reset))
+            kernel = "lmaze::" + abi.describe_step(env.params, N, auto_reset=bool(args.auto_reset),
+                                                   with_obs="u8" if args.obs_dtype == "u8" else True)
+            if args.one_launch:
+                kernel += " -- timed as ONE lmaze_rollout call of %d steps (rollout_shared_wave8_kernel where the planes stay on-die)" % args.steps
             perenv_kernel = None
             if args.per_env_layouts:
                 # BASELINE config 5 names an LDS-tiled maze per workgroup; at G*G a multiple of 256 the register-tiled
@@ -592,12 +614,12 @@ def main():
                 perenv_kernel = ("wave/register-tiled (one wave per env, layout in registers; measured faster than the LDS-tiled "
                                  "kernel at this G)" if "perenv_wave" in kernel else "LDS-tiled (a workgroup tiles ~8 KiB of layouts)")
         out = {
-            "metric": "env steps/sec (whole node), 1M parallel 11x11 mazes at 1/2/4/8 MI355X" if args.workload == "c3" and N == (1 << 20)
+            "metric": "env steps/sec (whole node), 1M parallel 11x11 mazes at 1/2/4/8 MI355X" if args.workload == "c3" and N == (1 << 20) and args.obs_dtype == "int32"
                       else "env steps/sec (whole node); workload '%s', NOT the configuration BASELINE.json's metric is quoted on" % args.workload,
             "workload_id": args.workload,
             "value": value, "unit": "env-steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "f32" if foveal else "int32", "data": "synthetic",
+            "vs_baseline": None, "dtype": "f32" if foveal else ("u8" if args.obs_dtype == "u8" else "int32"), "data": "synthetic",
             "per_rank_ms_per_step": {"min": min(per_rank) / args.steps * 1e3, "max": max(per_rank) / args.steps * 1e3,
                                      "all": [round(x / args.steps * 1e3, 6) for x in per_rank]},
             "config": {"workload": workload, "envs_per_gpu": N, "grid": G, "global_envs": world * N,
@@ -608,6 +630,7 @@ def main():
                        "actions": "uniform{0..%d} int32[%d,N] (%d MiB) on the device, row t %% rows at step t, torch Philox seed 1+rank"
                                   % (FOVEAL_ACTIONS[args.workload] - 1 if foveal else 3, R, (R * N * 4) >> 20),
                        "auto_reset": bool(args.auto_reset) or hier, "hip_graph": bool(args.graph),
+                       "one_launch_rollout": bool(args.one_launch),
                        "collective_backend": ("rccl" if backend == "nccl" else backend + " (REHEARSAL, ranks share a GPU)")
                        if dist is not None else None,
                        "launch_hint": int(env.params.launch_hint),
@@ -625,6 +648,9 @@ def main():
                                                    if pl and pl.get("first_ms_tuned") else None),
                          "frac_kept_allocation": (N * B / (pl["kept_ms_tuned"] * 1e-3) / 1e9 / HBM_PEAK_GBS
                                                   if pl and pl.get("kept_ms_tuned") else None),
+                         # the untuned library: first allocation AND launch_hint 0 (the per-shape default of the policy table)
+                         "frac_untuned_library": (N * B / (pl["first_ms_default"] * 1e-3) / 1e9 / HBM_PEAK_GBS
+                                                  if pl and pl.get("first_ms_default") else None),
                          "clock": "achieved / frac: ms_per_step (perf_counter around the timed launches, max over ranks); "
                                   "achieved_events / frac_events / kernel_ms_avg: HIP events on rank 0's launch stream",
                          "measured_ceiling": ceiling},

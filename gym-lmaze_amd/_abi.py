@@ -31,7 +31,8 @@ SYMBOLS = ("lmaze_abi_version", "lmaze_strerror", "lmaze_device_info", "lmaze_st
            "lmaze_episode_stats", "lmaze_bandwidth_probe", "lmaze_render_expanded", "lmaze_foveal_step", "lmaze_foveal_step_autoreset", "lmaze_foveal_reset", "lmaze_v1_set_foveal_goal",
            "lmaze_v5_planner_step", "lmaze_v5_hier_step", "lmaze_v6_safe_foveal_goal", "lmaze_expand_planes",
            "lmaze_foveal_visit_bytes", "lmaze_foveal_materialise_visit", "lmaze_foveal_load_visit",
-           "lmaze_describe_step", "lmaze_describe_foveal_step")
+           "lmaze_describe_step", "lmaze_describe_foveal_step", "lmaze_rollout",
+           "lmaze_step_u8", "lmaze_observe_u8")
 
 
 class LmazeParams(C.Structure):
@@ -137,6 +138,12 @@ def _load():
     lib.lmaze_foveal_materialise_visit.argtypes = [FP, FB, vp, i64, vp]
     lib.lmaze_foveal_load_visit.restype = C.c_int
     lib.lmaze_foveal_load_visit.argtypes = [FP, FB, vp, i64, vp]
+    lib.lmaze_step_u8.restype = C.c_int
+    lib.lmaze_step_u8.argtypes = [P, vp, vp, vp, vp, vp, vp, vp, vp, vp, i64, i32, u64, u64, i64, vp, vp, vp]
+    lib.lmaze_observe_u8.restype = C.c_int
+    lib.lmaze_observe_u8.argtypes = [P, vp, vp, vp, vp, vp, i64, vp]
+    lib.lmaze_rollout.restype = C.c_int
+    lib.lmaze_rollout.argtypes = [P, vp, vp, i32, vp, vp, vp, vp, vp, vp, vp, vp, vp, i64, i32, u64, u64, i64, vp]
     lib.lmaze_describe_step.restype = C.c_int
     lib.lmaze_describe_step.argtypes = [P, i64, i32, i32, C.c_char_p, i32]
     lib.lmaze_describe_foveal_step.restype = C.c_int
@@ -168,7 +175,8 @@ def device_info(device=0):
 def describe_step(params, n, auto_reset=False, with_obs=True):
     """The kernel / grid / launch policy the library would queue for n envs with these LmazeParams (lmaze_describe_step)."""
     buf = C.create_string_buffer(256)
-    check("lmaze_describe_step", lib.lmaze_describe_step(C.byref(params), int(n), 1 if auto_reset else 0, 1 if with_obs else 0, buf, 256))
+    check("lmaze_describe_step", lib.lmaze_describe_step(C.byref(params), int(n), 1 if auto_reset else 0,
+                                                         2 if with_obs == "u8" else (1 if with_obs else 0), buf, 256))
     return buf.value.decode("ascii", "replace")
 
 

@@ -32,6 +32,7 @@ static StepArgs make_args(const LmazeParams* p, const uint8_t* layout, const int
     a.done = done;
     a.goal_count = goal_count;
     a.obs = obs;
+    a.obs8 = nullptr;
     a.n = n;
     a.grid = p->grid;
     a.step_limit = p->step_limit;
@@ -122,6 +123,15 @@ int lmaze_describe_step(const LmazeParams* params, int64_t n, int32_t auto_reset
                            with_obs ? reinterpret_cast<int32_t*>(16) : nullptr, n);
     a.auto_reset = auto_reset ? 1 : 0;
     a.info = &info;
+    if (with_obs == 2) {             // the narrow-observation step (lmaze_step_u8)
+        if (params->layout_mode != LMAZE_LAYOUT_SHARED) return LMAZE_E_LAYOUT;
+        if (params->grid < 4) return LMAZE_E_GRID;
+        a.obs = nullptr;
+        a.obs8 = reinterpret_cast<uint8_t*>(16);
+        rc = (int)launch_step_u8(params->variant, true, a, nullptr);
+        if (rc) return rc;
+        return format_launch(info, text_host, len);
+    }
     rc = (int)launch_step(params->variant, true, a, params->layout_mode, nullptr);
     if (rc) return rc;
     return format_launch(info, text_host, len);
@@ -170,6 +180,68 @@ int lmaze_step_v0_autoreset(const LmazeParams* params, const uint8_t* layout, co
     a.epoch_in = epoch_in_dev;
     a.epoch_out = epoch_out_dev;
     return (int)launch_step(LMAZE_VARIANT_V0, true, a, params->layout_mode, (hipStream_t)stream);
+}
+
+int lmaze_step_u8(const LmazeParams* params, const uint8_t* layout, const int32_t* action, int32_t* ball_xy, int32_t* goal_xy,
+                  int32_t* step_count, float* reward, uint8_t* done, int32_t* goal_count, uint8_t* obs8, int64_t n,
+                  int32_t auto_reset, uint64_t seed, uint64_t epoch, int64_t env_base, const uint64_t* epoch_in_dev,
+                  uint64_t* epoch_out_dev, void* stream) {
+    int rc = check_params(params, n);
+    if (rc) return rc;
+    const bool v3 = params->variant == LMAZE_VARIANT_V3;
+    if (params->variant != LMAZE_VARIANT_V0 && !v3) return LMAZE_E_VARIANT;
+    if (params->layout_mode != LMAZE_LAYOUT_SHARED) return LMAZE_E_LAYOUT;
+    if (params->grid < 4) return LMAZE_E_GRID;        // a 16-byte store must not span more than two envs
+    if (!layout || !action || !ball_xy || !step_count || !reward || !done || (v3 && !goal_xy)) return LMAZE_E_NULL;
+    if (misaligned(ball_xy, 8) || misaligned(goal_xy, 8) || misaligned(obs8, 16)) return LMAZE_E_ALIGN;
+    if (bad_epoch_words(epoch_in_dev, epoch_out_dev)) return LMAZE_E_ALIGN;
+    StepArgs a = make_args(params, layout, action, ball_xy, v3 ? goal_xy : nullptr, step_count, reward, done, v3 ? nullptr : goal_count, nullptr, n);
+    a.obs8 = obs8;
+    a.auto_reset = auto_reset ? 1 : 0;
+    a.seed = seed;
+    a.epoch = epoch;
+    a.env_base = env_base;
+    a.epoch_in = epoch_in_dev;
+    a.epoch_out = epoch_out_dev;
+    a.goal_rw = v3 ? reinterpret_cast<int2*>(goal_xy) : nullptr;
+    return (int)launch_step_u8(params->variant, true, a, (hipStream_t)stream);
+}
+
+int lmaze_observe_u8(const LmazeParams* params, const uint8_t* layout, const int32_t* ball_xy, const int32_t* goal_xy,
+                     const uint8_t* mask, uint8_t* obs8, int64_t n, void* stream) {
+    int rc = check_params(params, n);
+    if (rc) return rc;
+    const bool v3 = params->variant == LMAZE_VARIANT_V3;
+    if (params->variant != LMAZE_VARIANT_V0 && !v3) return LMAZE_E_VARIANT;
+    if (params->layout_mode != LMAZE_LAYOUT_SHARED) return LMAZE_E_LAYOUT;
+    if (params->grid < 4) return LMAZE_E_GRID;
+    if (!layout || !ball_xy || !obs8 || (v3 && !goal_xy)) return LMAZE_E_NULL;
+    if (misaligned(ball_xy, 8) || misaligned(goal_xy, 8) || misaligned(obs8, 16)) return LMAZE_E_ALIGN;
+    StepArgs a = make_args(params, layout, nullptr, const_cast<int32_t*>(ball_xy), v3 ? goal_xy : nullptr, nullptr, nullptr, nullptr,
+                           nullptr, nullptr, n);
+    a.obs8 = obs8;
+    a.mask = mask;
+    return (int)launch_step_u8(params->variant, false, a, (hipStream_t)stream);
+}
+
+int lmaze_rollout(const LmazeParams* params, const uint8_t* layout, const int32_t* actions, int32_t T, int32_t* ball_xy,
+                  int32_t* goal_xy, int32_t* step_count, float* reward, uint8_t* done, int32_t* goal_count, int32_t* obs,
+                  float* reward_t, uint8_t* done_t, int64_t n, int32_t auto_reset, uint64_t seed, uint64_t epoch,
+                  int64_t env_base, void* stream) {
+    int rc = check_params(params, n);
+    if (rc) return rc;
+    const bool v3 = params->variant == LMAZE_VARIANT_V3;
+    if (params->variant != LMAZE_VARIANT_V0 && !v3) return LMAZE_E_VARIANT;
+    if (T < 0) return LMAZE_E_COUNT;
+    if (!layout || !actions || !ball_xy || !step_count || !reward || !done || (v3 && !goal_xy)) return LMAZE_E_NULL;
+    if (misaligned(ball_xy, 8) || misaligned(goal_xy, 8) || misaligned(obs, 16) || misaligned(layout, 16)) return LMAZE_E_ALIGN;
+    StepArgs a = make_args(params, layout, actions, ball_xy, v3 ? goal_xy : nullptr, step_count, reward, done, v3 ? nullptr : goal_count, obs, n);
+    a.auto_reset = auto_reset ? 1 : 0;
+    a.seed = seed;
+    a.epoch = epoch;
+    a.env_base = env_base;
+    a.goal_rw = v3 ? reinterpret_cast<int2*>(goal_xy) : nullptr;
+    return (int)launch_rollout(params->variant, a, params->layout_mode, actions, T, reward_t, done_t, (hipStream_t)stream);
 }
 
 int lmaze_step_v3_autoreset(const LmazeParams* params, const uint8_t* layout, const int32_t* action,

@@ -31,6 +31,7 @@ struct StepArgs {
     uint8_t* done;          // [N]
     int32_t* goal_count;    // [N] or null
     int32_t* obs;           // [N*G*G] or null
+    uint8_t* obs8;          // narrow observation uint8[N*G*G] (lmaze_step_u8 / lmaze_observe_u8), instead of obs
     int64_t n;
     int32_t grid;           // G when the kernel is not specialised on it
     int32_t step_limit;
@@ -89,6 +90,9 @@ inline bool bad_epoch_words(const uint64_t* in, const uint64_t* out) {
 inline bool grid_ok(int64_t blocks) { return blocks >= 1 && blocks <= (int64_t)0xFFFFFF; }
 
 hipError_t launch_step(int variant, bool do_step, const StepArgs& a, int layout_mode, hipStream_t s);
+hipError_t launch_step_u8(int variant, bool do_step, const StepArgs& a, hipStream_t s);
+hipError_t launch_rollout(int variant, const StepArgs& a, int layout_mode, const int32_t* actions, int32_t T, float* reward_t,
+                          uint8_t* done_t, hipStream_t s);
 hipError_t launch_reset(int variant, const ResetArgs& a, int layout_mode, hipStream_t s);
 hipError_t launch_expand(const ExpandArgs& a, hipStream_t s);
 hipError_t launch_probe(const void* src, void* dst, int64_t bytes, hipStream_t s);

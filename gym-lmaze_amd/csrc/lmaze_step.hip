@@ -747,6 +747,250 @@ __global__ __launch_bounds__(LMAZE_BLOCK) void step_shared_wave8_kernel(const St
 }
 
 // ------------------------------------------------------------------------------------
+// Narrow observation: the same bit mask in ONE BYTE per cell, uint8[N,G,G] -- the mask needs four
+// bits --, 37 + G*G bytes per env-step instead of 37 + 4 G*G (11x11: 158 against 521).  The int32 planes stay the
+// metric's mode; this is a separate workload with its own algorithmic bytes.  Shared layout, any G.
+// Phase 1 is the int32 kernel's (env_phase1); the render stripes the workgroup's EPB * G*G bytes with 16-byte stores,
+// 16 cells each, which straddle envs at every odd G: the static pattern comes from four byte-shifted copies of the
+// layout's bits laid out twice in a row (so that any 16 consecutive cells, wrapping into the next env, are four aligned
+// dword reads), the ball / goal bytes of the one or two envs a store touches are OR-ed in.
+// ------------------------------------------------------------------------------------
+template <int VARIANT, bool DO_STEP, int EPB>
+__global__ __launch_bounds__(LMAZE_BLOCK) void step_shared_u8_kernel(const StepArgs a) {
+    constexpr bool V3 = VARIANT == LMAZE_VARIANT_V3;
+    static_assert(EPB % 16 == 0 && EPB <= LMAZE_BLOCK, "a workgroup's byte range starts on a 16-byte boundary; one lane per env");
+    const int G = a.grid, CELLS = G * G;
+    const int PW = (2 * CELLS + 16 + 3) >> 2;             // dwords of one shifted copy: the pattern twice + 16 bytes of slack
+    extern __shared__ int4 lds4[];
+    uint32_t* patw = reinterpret_cast<uint32_t*>(lds4);                 // [4][PW] copy s = the doubled pattern starting at byte s
+    int* ballflat = reinterpret_cast<int*>(patw + 4 * PW);              // [EPB + 1]
+    int* goalflat = ballflat + EPB + 1;                                 // [EPB + 1]
+    int* maskflag = goalflat + EPB + 1;                                 // [EPB + 1]
+    uint16_t* spawn = reinterpret_cast<uint16_t*>(maskflag + EPB + 1);  // [CELLS]
+    uint8_t* lay = reinterpret_cast<uint8_t*>(spawn + ((CELLS + 1) & ~1));   // [CELLS]
+    __shared__ int spawn_count_s;
+    const int tid = threadIdx.x;
+    // chunks of EPB envs grid-stride, as step_shared_kernel: the set-up is paid once per workgroup and the next chunk's
+    // per-env inputs are loaded while the current one is rendered
+    const int64_t nchunks = (a.n + EPB - 1) / EPB;
+    int64_t chunk = blockIdx.x;
+    int64_t blockbase = chunk * EPB;
+    int nb = (int)min((int64_t)EPB, a.n - blockbase);
+    const bool masked = !DO_STEP && a.mask != nullptr;
+    const bool autoreset = DO_STEP && a.auto_reset;
+    const uint64_t epoch = autoreset ? launch_epoch(a.epoch, a.epoch_in) : 0;
+    if (autoreset) pass_epoch_on(a.epoch_in, a.epoch_out);
+    EnvIn in{};
+    if (tid < nb) in = load_env<VARIANT, DO_STEP>(a, blockbase + tid);
+    // set-up: ONE global round trip (the layout bytes, beside the env loads above), then everything from LDS
+    for (int i = tid; i < CELLS; i += LMAZE_BLOCK) lay[i] = a.layout[i];
+    __syncthreads();
+    uint8_t* patb = reinterpret_cast<uint8_t*>(patw);
+    for (int i = tid; i < 4 * PW; i += LMAZE_BLOCK) {                   // one dword of one copy per lane-iteration
+        const int s = i / PW, k = (i - s * PW) << 2;                    // bytes k .. k+3 of copy s = pattern bytes k+s .. of the doubled row
+        uint32_t w = 0;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            int c = k + s + j;
+            c -= c >= CELLS ? CELLS : 0;
+            c -= c >= CELLS ? CELLS : 0;
+            c = min(c, CELLS - 1);                                       // slack bytes past the doubled row: never selected
+            w |= (uint32_t)cell_bits<VARIANT>(lay[c]) << (8 * j);
+        }
+        patw[i] = w;
+    }
+    if (autoreset && tid < 64) {
+        const int cnt = wave_build_spawn_list<VARIANT>(lay, G, CELLS, spawn, tid);
+        if (tid == 0) spawn_count_s = cnt;
+    }
+    if (tid == 0) { ballflat[EPB] = -64; goalflat[EPB] = -64; maskflag[EPB] = 0; }
+    __syncthreads();
+  for (;;) {
+    const int64_t next = chunk + gridDim.x;
+    const bool has_next = next < nchunks;                               // uniform over the workgroup
+    EnvIn in_next{};
+    int nb_next = 0;
+    if (has_next) {
+        nb_next = (int)min((int64_t)EPB, a.n - next * EPB);
+        if (tid < nb_next) in_next = load_env<VARIANT, DO_STEP>(a, next * EPB + tid);
+    }
+    if (tid < EPB) {
+        int bf = -64, gf = -64, mf = 0;
+        if (tid < nb) {
+            const int64_t e = blockbase + tid;
+            int bc, gc;
+            const int cnt = autoreset ? spawn_count_s : 0;
+            env_phase1<VARIANT, DO_STEP>(a, lay, G, e, in, [&](uint4 d, int& pb, int& pg) { place_from_list<VARIANT>(spawn, cnt, d, pb, pg); }, epoch, bc, gc);
+            bf = bc;
+            if (V3 && gc >= 0) gf = gc;
+            if (masked) mf = a.mask[e] != 0;
+        }
+        ballflat[tid] = bf;
+        goalflat[tid] = gf;
+        maskflag[tid] = mf;
+    }
+    if (a.obs8 != nullptr) {
+    __syncthreads();
+    uint8_t* obs = a.obs8 + (size_t)blockbase * CELLS;
+    const int R = nb * CELLS;
+    if (!masked) {
+        const int nq = R >> 4;
+        for (int q = tid; q < nq; q += LMAZE_BLOCK) {
+            const int f0 = q << 4;
+            const int le = f0 / CELLS, c = f0 - le * CELLS;             // first cell of the store
+            const int sft = c & 3;
+            const uint32_t* src = patw + sft * PW + ((c - sft) >> 2);
+            uint32_t w[4] = {src[0], src[1], src[2], src[3]};
+            // ball (and v3 goal) bytes of env le at byte b - c, of env le + 1 at byte CELLS - c + b'
+            const int b0 = ballflat[le] - c, b1 = CELLS - c + ballflat[min(le + 1, EPB)];
+            if ((unsigned)b0 < 16u) w[b0 >> 2] |= (uint32_t)LMAZE_OBS_BALL << ((b0 & 3) << 3);
+            if ((unsigned)b1 < 16u && le + 1 < nb) w[b1 >> 2] |= (uint32_t)LMAZE_OBS_BALL << ((b1 & 3) << 3);
+            if (V3) {
+                const int g0 = goalflat[le] - c, g1 = CELLS - c + goalflat[min(le + 1, EPB)];
+                if ((unsigned)g0 < 16u) w[g0 >> 2] |= (uint32_t)LMAZE_OBS_GOAL << ((g0 & 3) << 3);
+                if ((unsigned)g1 < 16u && le + 1 < nb) w[g1 >> 2] |= (uint32_t)LMAZE_OBS_GOAL << ((g1 & 3) << 3);
+            }
+            if (a.launch_hint & 0x100) {                                // set by the launcher for large batches: non-temporal stores
+                typedef unsigned v4u __attribute__((ext_vector_type(4)));
+                v4u t = {w[0], w[1], w[2], w[3]};
+                __builtin_nontemporal_store(t, reinterpret_cast<v4u*>(obs) + q);
+            } else {
+                reinterpret_cast<uint4*>(obs)[q] = make_uint4(w[0], w[1], w[2], w[3]);
+            }
+        }
+        for (int f = (nq << 4) + tid; f < R; f += LMAZE_BLOCK) {        // ragged tail of the last chunk
+            const int le = f / CELLS, c = f - le * CELLS;
+            obs[f] = (uint8_t)(patb[c] | (ballflat[le] == c ? LMAZE_OBS_BALL : 0) | (V3 && goalflat[le] == c ? LMAZE_OBS_GOAL : 0));
+        }
+    } else {
+        for (int f = tid; f < R; f += LMAZE_BLOCK) {                    // masked re-render (after a masked reset): byte stores
+            const int le = f / CELLS, c = f - le * CELLS;
+            if (!maskflag[le]) continue;
+            obs[f] = (uint8_t)(patb[c] | (ballflat[le] == c ? LMAZE_OBS_BALL : 0) | (V3 && goalflat[le] == c ? LMAZE_OBS_GOAL : 0));
+        }
+    }
+    }
+    if (!has_next) break;
+    __syncthreads();                                                     // the per-env cells in LDS are rewritten by the next chunk
+    chunk = next;
+    blockbase = chunk * EPB;
+    nb = nb_next;
+    in = in_next;
+  }
+}
+
+// ------------------------------------------------------------------------------------
+// T steps in ONE launch for the same on-die 8x8 batches (lmaze_rollout_v0 / _v3): the wave-autonomous kernel above with
+// the step loop inside.  A wave's 64 envs stay in registers for the whole rollout -- envs are independent, nothing
+// synchronises --, each step's action row is fetched one step ahead, the planes are rewritten every step exactly as T
+// launches would (same 16 KiB per wave: they stay in L2) and the per-env state goes back once at the end; optional
+// per-step reward / done rows for the caller who needs the trajectory.  Step t draws its placements with epoch + t, as
+// the t-th of T lmaze_step_*_autoreset calls would.  Bit-identical to those T calls.
+// ------------------------------------------------------------------------------------
+struct RolloutArgs {
+    const int32_t* actions;   // [T, N]
+    float* reward_t;          // [T, N] or null
+    uint8_t* done_t;          // [T, N] or null
+    int32_t T;
+};
+
+template <int VARIANT, int EPW>
+__global__ __launch_bounds__(LMAZE_BLOCK) void rollout_shared_wave8_kernel(const StepArgs a, const RolloutArgs ro) {
+    constexpr bool V3 = VARIANT == LMAZE_VARIANT_V3;
+    constexpr int G = 8, CELLS = 64;
+    const int lane = threadIdx.x & 63;
+    const int64_t base = ((int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)) * EPW;
+    if (base >= a.n) return;
+    const int nb = (int)min((int64_t)EPW, a.n - base);
+    const bool autoreset = a.auto_reset != 0;
+    const bool live = lane < nb;
+    const int64_t e = base + lane;
+    const int myc = a.layout[lane];
+    int2 b = make_int2(1, 1), g = make_int2(-1, -1);
+    int sc = 0, was_done = 0, hits = 0, act_next = -1;
+    float r = 0.0f;
+    if (live) {
+        b = a.ball[e];
+        if (V3) g = a.goal[e];
+        sc = a.step_count[e];
+        if (!V3) r = a.reward[e];
+        if (autoreset) was_done = a.done[e];
+        act_next = ro.actions[e];
+    }
+    const int mypat = cell_bits<VARIANT>((uint8_t)myc);
+    const int p4 = (lane & 15) << 2;
+    const int4 pat4 = make_int4(__shfl(mypat, p4, 64), __shfl(mypat, p4 + 1, 64), __shfl(mypat, p4 + 2, 64),
+                                __shfl(mypat, p4 + 3, 64));
+    const unsigned long long ok = __ballot(interior(lane, G) && spawn_ok<VARIANT>((uint8_t)myc));
+    int4* obs4 = a.obs ? reinterpret_cast<int4*>(a.obs + (size_t)base * CELLS) : nullptr;
+    bool dn = false;
+    for (int t = 0; t < ro.T; ++t) {
+        const int act = act_next;
+        if (t + 1 < ro.T && live) act_next = ro.actions[(size_t)(t + 1) * a.n + e];      // next step's row, in flight over this step
+        float r_in = r;
+        if (autoreset && was_done) {   // reference reset(): as step_shared_wave8_kernel, with this step's epoch
+            const uint4 d = env_draw(a.seed, a.epoch + (uint64_t)t, a.env_base + e);
+            const int count = __popcll(ok);
+            if (V3) {
+                int kg = -1;
+                if (count > 0) {
+                    kg = (int)__umulhi(d.x, (uint32_t)count);
+                    const int gc = kth_set_bit(ok, kg);
+                    g = make_int2(gc / G, gc % G);
+                }
+                if (count > 1) {
+                    int kb = (int)__umulhi(d.y, (uint32_t)(count - 1));
+                    kb += (kb >= kg);
+                    const int bc = kth_set_bit(ok, kb);
+                    b = make_int2(bc / G, bc % G);
+                }
+            } else if (count > 0) {
+                const int bc = kth_set_bit(ok, (int)__umulhi(d.y, (uint32_t)count));
+                b = make_int2(bc / G, bc % G);
+            }
+            sc = 0;         // v0:110
+            r_in = -0.0f;   // v0:109
+        }
+        int bx = clampi(b.x, 0, G - 1), by = clampi(b.y, 0, G - 1);
+        sc += 1;            // v0:151, v3:225
+        int ox, oy;
+        decode_action(act, ox, oy);
+        const int tx = clampi(bx + ox, 0, G - 1), ty = clampi(by + oy, 0, G - 1);
+        const uint8_t c = (uint8_t)__shfl(myc, tx * G + ty, 64);      // v0:172, v3:251 -- every lane takes part
+        const bool hit = transition_rule<VARIANT>(a, c, ox, oy, tx, ty, sc, r_in, g.x, g.y, bx, by, r, dn);
+        hits += hit ? 1 : 0;
+        b = make_int2(bx, by);
+        was_done = dn ? 1 : 0;
+        if (live) {
+            if (ro.reward_t) ro.reward_t[(size_t)t * a.n + e] = r;
+            if (ro.done_t) ro.done_t[(size_t)t * a.n + e] = dn ? 1 : 0;
+        }
+        if (obs4) {
+            const int ball_cell = b.x * G + b.y;
+            const int goal_cell = (V3 && g.x >= 0 && g.x < G && g.y >= 0 && g.y < G) ? g.x * G + g.y : -8;
+#pragma unroll
+            for (int k = 0; k < EPW / 4; ++k) {
+                const int le = (lane >> 4) + 4 * k;
+                const int bc = __shfl(ball_cell, le, 64);
+                const int gc = V3 ? __shfl(goal_cell, le, 64) : -8;
+                int4 v = pat4;
+                or_at(v, bc - p4, LMAZE_OBS_BALL);
+                if (V3) or_at(v, gc - p4, LMAZE_OBS_GOAL);
+                if (le < nb) obs4[lane + 64 * k] = v;
+            }
+        }
+    }
+    if (live && ro.T > 0) {
+        a.ball[e] = b;
+        if (V3 && autoreset) a.goal_rw[e] = g;
+        a.step_count[e] = sc;
+        a.reward[e] = r;
+        a.done[e] = dn ? 1 : 0;
+        if (hits && a.goal_count) a.goal_count[e] += hits;
+    }
+}
+
+// ------------------------------------------------------------------------------------
 // host launchers
 // ------------------------------------------------------------------------------------
 
@@ -1027,6 +1271,90 @@ static hipError_t dispatch_grid(const StepArgs& a, int layout_mode, hipStream_t 
         case 32: return launch_one<32, VARIANT, DO_STEP>(a, layout_mode, s);
         default: return launch_one<0, VARIANT, DO_STEP>(a, layout_mode, s);
     }
+}
+
+hipError_t launch_step(int variant, bool do_step, const StepArgs& a, int layout_mode, hipStream_t s);
+
+#ifndef LMAZE_U8_DEFAULT_SEL
+#define LMAZE_U8_DEFAULT_SEL 1
+#endif
+#ifndef LMAZE_U8_DEFAULT_CHUNKS
+#define LMAZE_U8_DEFAULT_CHUNKS 2
+#endif
+// narrow (uint8) observation, shared layout.  launch_hint bits 10-11: envs per workgroup, 1: 256, 2: 128, 3: 64 (0 = default)
+template <int EPB>
+static hipError_t launch_step_u8_epb(int variant, bool do_step, const StepArgs& a, hipStream_t s) {
+    const int cells = a.grid * a.grid, pw = (2 * cells + 16 + 3) >> 2;
+    const size_t lds = ((size_t)4 * pw * 4 + 3 * (size_t)(EPB + 1) * 4 + (size_t)((cells + 1) & ~1) * 2 + (size_t)cells + 15) & ~(size_t)15;
+    // launch_hint bits 4-7: chunks of EPB envs per workgroup (0 = default)
+    int m = (a.launch_hint >> 4) & 15;
+    if (m == 0) m = LMAZE_U8_DEFAULT_CHUNKS;
+    const int64_t nchunks = (a.n + EPB - 1) / EPB;
+    const int64_t blocks = (nchunks + m - 1) / m;
+    if (!grid_ok(blocks)) return hipErrorInvalidConfiguration;
+    if (a.info) {
+        char name[96];
+        snprintf(name, sizeof(name), "step_shared_u8_kernel<v%d, %s, %d>", variant, do_step ? "step" : "observe", EPB);
+        describe_launch(a.info, name, EPB, 0, m, false, blocks, LMAZE_BLOCK, lds);
+        return hipSuccess;
+    }
+    const dim3 grid((unsigned)blocks), block(LMAZE_BLOCK);
+    StepArgs b = a;
+    // more than 64 MiB of planes: streamed (1M x 11x11, 127 MB: 31.2 us per step against 33.3 with plain stores)
+    b.launch_hint = (a.launch_hint & ~0x100) | ((size_t)a.n * cells > ((size_t)64 << 20) ? 0x100 : 0);
+    if (variant == LMAZE_VARIANT_V3) {
+        if (do_step) hipLaunchKernelGGL((step_shared_u8_kernel<LMAZE_VARIANT_V3, true, EPB>), grid, block, lds, s, b);
+        else hipLaunchKernelGGL((step_shared_u8_kernel<LMAZE_VARIANT_V3, false, EPB>), grid, block, lds, s, b);
+    } else {
+        if (do_step) hipLaunchKernelGGL((step_shared_u8_kernel<LMAZE_VARIANT_V0, true, EPB>), grid, block, lds, s, b);
+        else hipLaunchKernelGGL((step_shared_u8_kernel<LMAZE_VARIANT_V0, false, EPB>), grid, block, lds, s, b);
+    }
+    return hipGetLastError();
+}
+
+hipError_t launch_step_u8(int variant, bool do_step, const StepArgs& a, hipStream_t s) {
+    if (a.n == 0) return hipSuccess;
+    int sel = (a.launch_hint >> 10) & 3;
+    if (sel == 0) sel = LMAZE_U8_DEFAULT_SEL;
+    if (sel == 1) return launch_step_u8_epb<256>(variant, do_step, a, s);
+    if (sel == 2) return launch_step_u8_epb<128>(variant, do_step, a, s);
+    return launch_step_u8_epb<64>(variant, do_step, a, s);
+}
+
+// T steps: ONE launch where the batch is an on-die shared 8x8 one (see rollout_shared_wave8_kernel), else T launches of
+// the step kernel, step t with the action row t, epoch + t and, when given, the per-step reward / done rows copied out.
+hipError_t launch_rollout(int variant, const StepArgs& a0, int layout_mode, const int32_t* actions, int32_t T, float* reward_t,
+                          uint8_t* done_t, hipStream_t s) {
+    if (T <= 0 || a0.n == 0) return hipSuccess;
+    const bool on_die8 = layout_mode == LMAZE_LAYOUT_SHARED && a0.grid == 8 &&
+                         (a0.obs == nullptr || (size_t)a0.n * 64 * 4 <= kNonTemporalObsBytes) && (a0.launch_hint & 0x100) == 0;
+    if (on_die8) {
+        RolloutArgs ro{actions, reward_t, done_t, T};
+        const int epw = 64, wpb = a0.n >= 65536 ? 4 : 1;
+        const int64_t waves = (a0.n + epw - 1) / epw, blocks = (waves + wpb - 1) / wpb;
+        if (!grid_ok(blocks)) return hipErrorInvalidConfiguration;
+        if (a0.info) {
+            char name[96];
+            snprintf(name, sizeof(name), "rollout_shared_wave8_kernel<v%d, %d> T=%d", variant, epw, T);
+            describe_launch(a0.info, name, epw * wpb, 0, 1, false, blocks, 64 * wpb, 0);
+            return hipSuccess;
+        }
+        if (variant == LMAZE_VARIANT_V3)
+            hipLaunchKernelGGL((rollout_shared_wave8_kernel<LMAZE_VARIANT_V3, 64>), dim3((unsigned)blocks), dim3(64 * wpb), 0, s, a0, ro);
+        else
+            hipLaunchKernelGGL((rollout_shared_wave8_kernel<LMAZE_VARIANT_V0, 64>), dim3((unsigned)blocks), dim3(64 * wpb), 0, s, a0, ro);
+        return hipGetLastError();
+    }
+    for (int32_t t = 0; t < T; ++t) {
+        StepArgs a = a0;
+        a.action = actions + (size_t)t * a0.n;
+        a.epoch = a0.epoch + (uint64_t)t;
+        hipError_t rc = launch_step(variant, true, a, layout_mode, s);
+        if (rc != hipSuccess || a0.info) return rc;
+        if (reward_t && (rc = hipMemcpyAsync(reward_t + (size_t)t * a0.n, a0.reward, (size_t)a0.n * 4, hipMemcpyDeviceToDevice, s)) != hipSuccess) return rc;
+        if (done_t && (rc = hipMemcpyAsync(done_t + (size_t)t * a0.n, a0.done, (size_t)a0.n, hipMemcpyDeviceToDevice, s)) != hipSuccess) return rc;
+    }
+    return hipSuccess;
 }
 
 hipError_t launch_step(int variant, bool do_step, const StepArgs& a, int layout_mode, hipStream_t s) {

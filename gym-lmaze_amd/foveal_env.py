@@ -329,7 +329,7 @@ class LmazeFovealVecEnv(object):
         1.5 %.  placement_trials=K (K > 1): first the step is timed (uncapped policy, the sensitive one) on K - 1 further
         allocations of the observation buffer and the fastest becomes `self.obs` -- possibly a NEW tensor; as for
         LmazeVecEnv.autotune, where the driver placed the write target is worth up to 8 % uncapped and 2-3 % at the tuned
-        cap (tools/placement_study4.py).  Returns {hint: ms}."""
+        cap (tools/placement_pmc.py, LAB_NOTES.md R3.2).  Returns {hint: ms}."""
         N = self.num_envs
         for t in (actions, goals):
             if t is not None and not (isinstance(t, torch.Tensor) and t.dtype == torch.int32 and t.dim() == 2
@@ -408,6 +408,16 @@ class LmazeFovealVecEnv(object):
                     e1.record()
                     e1.synchronize()
                     self.placement[name] = round(e0.elapsed_time(e1) / steps, 5)
+                # ... and under the library default policy (launch_hint 0): what an untuned LmazeFovealVecEnv runs
+                self.params.launch_hint = 0
+                self.bufs.obs = first_alloc.data_ptr() if first_alloc is not None else kept_ptr
+                run(3)
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                run(steps)
+                e1.record()
+                e1.synchronize()
+                self.placement["first_ms_default"] = round(e0.elapsed_time(e1) / steps, 5)
                 self.bufs.obs = kept_ptr
                 first_alloc = None
             self.restore(snap)

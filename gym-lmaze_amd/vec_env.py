@@ -57,6 +57,9 @@ class LmazeVecEnv(object):
     per_env_layouts   uint8[N,G,G] (numpy or torch): every env has its own maze
     env_base          global index of local env 0 when the batch is one shard of a larger
                       one (keys the reset draws; see include/lmaze.h lmaze_reset)
+    obs_dtype         "int32" (default; the compact planes BASELINE's metric is quoted on) or "u8": the same LMAZE_OBS_* bit
+                      mask in one byte per cell, uint8[N,G,G], 37 + G*G bytes per env-step instead of 37 + 4 G*G (shared
+                      layouts, G >= 4; lmaze_step_u8 -- no launch-policy knobs, no one-launch rollout)
     online_autotune   OPT-IN (default False: the library's default launch policy, nothing timed).  True, on
                       large shared-layout batches only (the streaming regime): time the launch policies on
                       the caller's own first ~200 steps, in the caller's own loop -- after 100 untimed steps they cycle
@@ -70,7 +73,7 @@ class LmazeVecEnv(object):
 
     def __init__(self, num_envs, variant="v0", layout=None, per_env_layouts=None, device=None,
                  expansion=None, step_limit=None, rewards=None, seed=0, env_base=0, validate=True,
-                 online_autotune=False):
+                 online_autotune=False, obs_dtype="int32"):
         if variant not in VARIANTS:
             raise ValueError("unknown variant %r (have %s)" % (variant, sorted(VARIANTS)))
         spec = VARIANTS[variant]
@@ -135,14 +138,19 @@ class LmazeVecEnv(object):
         self.goal_count = view("goal_count", 4 * N, torch.int32, (N,))
         self._done_u8 = view("done", N, torch.uint8, (N,))
         self.done = self._done_u8.view(torch.bool)
-        self.obs = torch.zeros((N, G, G), dtype=torch.int32, device=self.device)
+        if obs_dtype not in ("int32", "u8"):
+            raise ValueError("obs_dtype must be 'int32' or 'u8'")
+        self._u8 = obs_dtype == "u8"
+        if self._u8 and (self.layout_mode != _abi.LAYOUT_SHARED or G < 4):
+            raise ValueError("obs_dtype='u8' needs a shared layout with G >= 4")
+        self.obs = torch.zeros((N, G, G), dtype=torch.uint8 if self._u8 else torch.int32, device=self.device)
         self._expanded = None
 
         self.params = _abi.make_params(spec["id"], G, self.layout_mode, self.step_limit, *self.rewards)
         self._pp = C.byref(self.params)
         self._cmask = (C.c_int32 * len(self.channel_mask))(*self.channel_mask)
         self._bind_pointers()
-        streaming = self.layout_mode == _abi.LAYOUT_SHARED and N * G * G * 4 > (192 << 20)
+        streaming = self.layout_mode == _abi.LAYOUT_SHARED and N * G * G * 4 > (192 << 20) and not self._u8
         self._tuner = OnlineTuner(self.ONLINE_CANDIDATES) if (online_autotune and streaming) else None
         if self._tuner is not None:
             _log.info("gym-lmaze_amd: online launch-policy tuning on for the next ~%d steps of this %d-env batch",
@@ -263,6 +271,18 @@ class LmazeVecEnv(object):
 
     def _launch_step_raw(self, action_ptr, obs_ptr, auto_reset, epoch_slot=None):
         lib, N, st = _abi.lib, self.num_envs, self._stream()
+        if self._u8:
+            epoch, e_in, e_out = 0, None, None
+            if auto_reset and epoch_slot is None:
+                epoch = self._epoch
+                self._epoch += 1
+            elif auto_reset:
+                e_in, e_out = self._epoch_word_ptrs(int(epoch_slot))
+            rc = lib.lmaze_step_u8(self._pp, self._p_layout, action_ptr, self._p_ball, self._p_goal if self._is_v3 else None,
+                                   self._p_step, self._p_reward, self._p_done, None if self._is_v3 else self._p_gc, obs_ptr, N,
+                                   1 if auto_reset else 0, self.seed & (2 ** 64 - 1), epoch, self.env_base, e_in, e_out, st)
+            _abi.check("lmaze_step_u8", rc)
+            return
         if auto_reset:
             seed = self.seed & (2 ** 64 - 1)
             if epoch_slot is None:
@@ -327,16 +347,18 @@ class LmazeVecEnv(object):
         (round 1) a pair that is fast in a burst and slower sustained could win -- (4, 1) measured 82.6 us while
         tuning and 88.6 us over the 300 timed steps that followed, next to 83.4 for the default.
         placement_trials=K (K > 1): before the policies are timed, K - 1 further observation buffers are allocated and
-        the step is timed on each with the (5, 2) policy; the fastest buffer becomes `self.obs` (re-read the attribute:
-        it may be a NEW tensor), the others are freed.  Where the driver placed the 500-MB write target decides whether
-        policies with more than 3 workgroups per CU run at 82 or at 100 us (tools/placement_study3.py: 3 of 10
-        allocations of one process were fast ones; swapping only the obs pointer of a fast and a slow env swaps their
-        times) -- presumably the size of the physical fragments behind it, i.e. the TLB reach of thousands of
-        concurrent 31-KiB write streams.  `self.placement` records the trial times.
+        the step is timed on each with the (5, 2) policy; the fastest becomes the storage of `self.obs` (the SAME tensor
+        object: references the caller holds stay valid), the others are freed.  Where the driver placed the 500-MB write
+        target is worth 3-5 % at the default policy and up to 20 % under a capped one.  Round 3 measured what differs
+        (tools/placement_pmc.py under rocprofv3 --pmc, LAB_NOTES.md R3.2): NOT address translation (UTCL1 misses 0.06 % of
+        requests on fast and slow buffers alike) but the memory side -- 25 % more DRAM write-credit stall cycles
+        (TCC_EA0_WRREQ_DRAM_CREDIT_STALL) on the slow allocations, i.e. which channels / banks the buffer's physical pages
+        load; a 2-MiB-aligned arena shows the same spread.  `self.placement` records the trial times and, under the policy
+        finally chosen, the first allocation's time beside the kept one's (bench.py: roofline.frac_first_allocation).
         Returns {(per_cu, chunks): ms per step}.  Only the shared-layout kernel has these knobs."""
         obs_bytes = self.num_envs * self.grid * self.grid * 4
-        if self.layout_mode != _abi.LAYOUT_SHARED or obs_bytes <= (192 << 20):
-            return {}       # the knobs only pay in the streaming (non-temporal store) regime
+        if self.layout_mode != _abi.LAYOUT_SHARED or obs_bytes <= (192 << 20) or self._u8:
+            return {}       # the knobs only pay in the streaming (non-temporal store) regime; the u8 kernel has none
         cands = [tuple(c) if isinstance(c, (tuple, list)) else (int(c), 1) for c in (candidates or self.CANDIDATES)]
         N = self.num_envs
         if actions is None:
@@ -433,6 +455,20 @@ class LmazeVecEnv(object):
                     e1.record()
                     e1.synchronize()
                     pair[name] = round(e0.elapsed_time(e1) / steps, 5)
+                # ... and under the LIBRARY DEFAULT policy (launch_hint 0), which is what LmazeVecEnv(...) without any tuning runs
+                self.params.launch_hint = 0
+                ptr = first_alloc.data_ptr() if first_alloc is not None else self._p_obs
+                for _ in range(3):
+                    self._launch_step(base + (t % R) * stride, ptr, auto_reset)
+                    t += 1
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                for _ in range(steps):
+                    self._launch_step(base + (t % R) * stride, ptr, auto_reset)
+                    t += 1
+                e1.record()
+                e1.synchronize()
+                pair["first_ms_default"] = round(e0.elapsed_time(e1) / steps, 5)
                 self.placement.update(pair)
                 first_alloc = None
             self._state.copy_(snap)
@@ -445,22 +481,51 @@ class LmazeVecEnv(object):
         self.observe()
         return timings
 
-    def rollout(self, actions, auto_reset=True, device_epoch=False):
+    def rollout(self, actions, auto_reset=True, device_epoch=False, trajectory=False):
         """T steps over a device tensor int32[T,N] of actions, one kernel per step, no host
         sync (capture_rollout() records it into a hipGraph for launch-bound batch sizes).
         device_epoch: keep the reset epoch on the device (what capture_rollout uses; bit-identical to the
-        host-counted epochs when begin_replay(T) precedes it).  Returns the final (obs, reward, done)."""
+        host-counted epochs when begin_replay(T) precedes it).  Returns the final (obs, reward, done); trajectory=True adds
+        every step's reward float32[T,N] and done bool[T,N].  On-die shared 8x8 batches (BASELINE's 65 536 x 8x8) run the
+        whole rollout as ONE launch (include/lmaze.h lmaze_rollout)."""
         if not (isinstance(actions, torch.Tensor) and actions.dtype == torch.int32 and actions.dim() == 2
                 and actions.shape[1] == self.num_envs and actions.device == self.device and actions.is_contiguous()):
             raise ValueError("rollout() wants a contiguous int32[T,N] tensor on %s" % (self.device,))
         base, stride = actions.data_ptr(), self.num_envs * 4
+        T, N = int(actions.shape[0]), self.num_envs
+        if not device_epoch and self._tuner is None and not self._u8:
+            # lmaze_rollout: ONE launch for on-die shared 8x8 batches (a wave keeps its 64 envs in registers across the T
+            # steps), T launches from inside the library otherwise; bit-identical to T step() calls either way
+            rew_t = torch.empty((T, N), dtype=torch.float32, device=self.device) if trajectory else None
+            done_t = torch.empty((T, N), dtype=torch.uint8, device=self.device) if trajectory else None
+            with self._guard():
+                rc = _abi.lib.lmaze_rollout(self._pp, self._p_layout, base, T, self._p_ball,
+                                            self._p_goal if self._is_v3 else None, self._p_step, self._p_reward, self._p_done,
+                                            None if self._is_v3 else self._p_gc, self._p_obs,
+                                            rew_t.data_ptr() if trajectory else None, done_t.data_ptr() if trajectory else None,
+                                            N, 1 if auto_reset else 0, self.seed & (2 ** 64 - 1), self._epoch, self.env_base,
+                                            self._stream())
+            _abi.check("lmaze_rollout", rc)
+            if auto_reset:
+                self._epoch += T
+            if trajectory:
+                return self.obs, self.reward, self.done, rew_t, done_t.view(torch.bool)
+            return self.obs, self.reward, self.done
+        if trajectory:
+            raise ValueError("rollout(trajectory=True) is not available with a device-resident epoch or while the online tuner runs")
         with self._guard():
             for t in range(actions.shape[0]):
                 self._launch_step(base + t * stride, self._p_obs, auto_reset, t if device_epoch else None)
         return self.obs, self.reward, self.done
 
-    def observe(self):
+    def observe(self, mask_ptr=None):
         """Re-render the compact planes of the current state (no transition)."""
+        if self._u8:
+            with self._guard():
+                rc = _abi.lib.lmaze_observe_u8(self._pp, self._p_layout, self._p_ball, self._p_goal if self._is_v3 else None,
+                                               mask_ptr, self._p_obs, self.num_envs, self._stream())
+            _abi.check("lmaze_observe_u8", rc)
+            return self.obs
         with self._guard():
             rc = _abi.lib.lmaze_observe(self._pp, self._p_layout, self._p_ball,
                                         self._p_goal if self._is_v3 else None, self._p_obs,
@@ -484,10 +549,12 @@ class LmazeVecEnv(object):
         with self._guard():
             rc = _abi.lib.lmaze_reset(self._pp, self._p_layout, m_ptr, self.seed & (2 ** 64 - 1), self._epoch,
                                       self.env_base, self._p_ball, self._p_goal if self._is_v3 else None,
-                                      self._p_step, self._p_reward, self._p_done, self._p_obs,
+                                      self._p_step, self._p_reward, self._p_done, None if self._u8 else self._p_obs,
                                       self.num_envs, self._stream())
         _abi.check("lmaze_reset", rc)
         self._epoch += 1
+        if self._u8:
+            self.observe(mask_ptr=m_ptr)       # the narrow planes of the envs that were reset
         return self.obs
 
     def set_state(self, ball_xy=None, goal_xy=None, step_count=None, reward=None, goal_count=None, done=None):
@@ -506,8 +573,9 @@ class LmazeVecEnv(object):
             if self._expanded is None:
                 self._expanded = torch.empty((N, Cn, G * E, G * E), dtype=torch.float32, device=self.device)
             out = self._expanded
+        src = self.obs.to(torch.int32) if self._u8 else self.obs      # the x E render reads int32 planes
         with self._guard():
-            rc = _abi.lib.lmaze_render_expanded(self._p_obs, G, E, self._cmask, Cn, out.data_ptr(), N,
+            rc = _abi.lib.lmaze_render_expanded(src.data_ptr(), G, E, self._cmask, Cn, out.data_ptr(), N,
                                                 self._stream())
         _abi.check("lmaze_render_expanded", rc)
         return out

@@ -112,7 +112,8 @@ int lmaze_device_info(int device, int32_t* cu_count_host, char* name_host, int32
  * Which kernel, grid and launch policy lmaze_step_v0 / _v3 (auto_reset != 0: the *_autoreset forms) would queue for n
  * envs with these params -- decided by the very code that launches, nothing is queued or dereferenced.  text_host
  * receives one line, e.g. "step_shared_kernel<11, v0, step, 32, nt> grid=32768 block=256 lds=20480
- * envs_per_workgroup=32 workgroups_per_cu=0 chunks=1" (workgroups_per_cu 0 = no cap).  For bench.py's
+ * envs_per_workgroup=32 workgroups_per_cu=0 chunks=1" (workgroups_per_cu 0 = no cap; with_obs: 0 transition only, 1 the
+ * int32 planes, 2 the narrow planes of lmaze_step_u8).  For bench.py's
  * roofline.kernel and the launch-policy guard test; no reference counterpart.
  */
 int lmaze_describe_step(const LmazeParams* params, int64_t n, int32_t auto_reset, int32_t with_obs, char* text_host,
@@ -203,6 +204,38 @@ int lmaze_step_v3_autoreset(const LmazeParams* params, const uint8_t* layout, co
                             uint8_t* done, int32_t* obs, int64_t n, uint64_t seed, uint64_t epoch,
                             int64_t env_base, const uint64_t* epoch_in_dev, uint64_t* epoch_out_dev,
                             void* stream);
+
+/*
+ * The step with a NARROW observation: the same LMAZE_OBS_* bit mask in one byte per cell, obs8 uint8[N,G,G] (16-byte
+ * aligned, nullable), 37 + G*G bytes per env-step instead of 37 + 4 G*G.  Shared layouts only (LMAZE_E_LAYOUT
+ * otherwise); params->variant selects the rules, goal_xy is v3's (read; rewritten for reset envs), goal_count v0's (nullable).
+ * auto_reset != 0 fuses the reset in exactly as lmaze_step_*_autoreset (seed, epoch, env_base, device-resident epoch words).
+ * State and obs8 are what lmaze_step_v0 / _v3 leave, each plane dword narrowed to a byte.  The int32 planes remain the mode
+ * BASELINE's metric is quoted on; this one has its own algorithmic bytes (bench.py --obs-dtype u8).
+ * lmaze_observe_u8: the planes of the current state without stepping (mask != NULL: only the envs with mask[i] != 0).
+ */
+int lmaze_step_u8(const LmazeParams* params, const uint8_t* layout, const int32_t* action, int32_t* ball_xy, int32_t* goal_xy,
+                  int32_t* step_count, float* reward, uint8_t* done, int32_t* goal_count, uint8_t* obs8, int64_t n,
+                  int32_t auto_reset, uint64_t seed, uint64_t epoch, int64_t env_base, const uint64_t* epoch_in_dev,
+                  uint64_t* epoch_out_dev, void* stream);
+int lmaze_observe_u8(const LmazeParams* params, const uint8_t* layout, const int32_t* ball_xy, const int32_t* goal_xy,
+                     const uint8_t* mask, uint8_t* obs8, int64_t n, void* stream);
+
+/*
+ * T steps of N v0 / v3 mazes over a pre-generated action tensor int32[T,N] (row t = step t): exactly T calls of
+ * lmaze_step_v0 / _v3 -- with auto_reset != 0 of the *_autoreset forms, step t drawing with epoch + t -- with
+ * bit-identical state and planes at the end (params->variant selects the rules; goal_xy for v3 only, goal_count for v0
+ * only, both nullable as in the step calls).  reward_t float[T,N] / done_t uint8[T,N] (nullable) receive every step's
+ * reward and done row.  Where the batch's planes stay on the die -- a shared 8x8 layout, up to 192 MiB of planes, e.g.
+ * BASELINE's 65 536 x 8x8 -- the whole rollout is ONE launch: a wave keeps its 64 envs in registers across the T steps,
+ * the planes are rewritten every step as T launches would, the per-env state goes back once at the end (a step costs 6 us
+ * as a launch of its own, a third of it launch gap; lmaze_describe_step names the step kernel, this call its rollout
+ * form).  Every other shape runs T launches of the step kernel from inside this call.  The caller advances its epoch by T.
+ */
+int lmaze_rollout(const LmazeParams* params, const uint8_t* layout, const int32_t* actions, int32_t T, int32_t* ball_xy,
+                  int32_t* goal_xy, int32_t* step_count, float* reward, uint8_t* done, int32_t* goal_count, int32_t* obs,
+                  float* reward_t, uint8_t* done_t, int64_t n, int32_t auto_reset, uint64_t seed, uint64_t epoch,
+                  int64_t env_base, void* stream);
 
 /*
  * Reference-layout observation: replaces the 5-deep upsample loop (v0:217-234,

@@ -609,3 +609,94 @@ def test_wave_autonomous_8x8_kernel_equals_the_lds_kernel_and_the_oracle(variant
         else:
             assert (_np(wave.observe()) == obs_ref).all() and (_np(lds.observe()) == obs_ref).all(), t
     assert wave._epoch == lds._epoch == epoch
+
+
+# ---------------------------------------------------------------- T steps in one launch (lmaze_rollout)
+@pytest.mark.parametrize("variant", ["v0", "v3"])
+@pytest.mark.parametrize("auto_reset", [False, True])
+@pytest.mark.parametrize("T", [1, 7, 256])
+def test_rollout_in_one_launch_equals_T_step_calls(variant, auto_reset, T):
+    """lmaze_rollout on BASELINE's C2 shape (65 536 x 8x8, the rollout kernel: a wave keeps its 64 envs in registers
+    across the T steps) and on ragged batches: state, planes and every step's reward / done row are bit-identical to T
+    calls of lmaze_step_* (with the fused reset: the same placements, epoch + t)."""
+    lay = PKG.layouts.GRID_8_BORDERED
+    for N in ((65536, 1000, 70) if T != 256 else (65536,)):
+        one = PKG.LmazeVecEnv(N, variant=variant, layout=lay, seed=11, env_base=3)
+        ref = PKG.LmazeVecEnv(N, variant=variant, layout=lay, seed=11, env_base=3)
+        what = PKG._abi.describe_step(one.params, N, auto_reset)
+        assert "step_shared_wave8_kernel" in what
+        gen = torch.Generator(device="cuda").manual_seed(5 + T)
+        acts = torch.randint(-1, 6, (T, N), dtype=torch.int32, device="cuda", generator=gen)    # incl. out-of-range ids
+        obs, rew, done, rew_t, done_t = one.rollout(acts, auto_reset=auto_reset, trajectory=True)
+        for t in range(T):
+            o, r, d, _ = ref.step(acts[t], auto_reset=auto_reset)
+            assert (rew_t[t].view(torch.int32) == r.view(torch.int32)).all(), (N, t)
+            assert (done_t[t] == d).all(), (N, t)
+        h1, h2 = one.host_state(), ref.host_state()
+        for k in h1:
+            assert (np.ascontiguousarray(h1[k]).view(np.uint8) == np.ascontiguousarray(h2[k]).view(np.uint8)).all(), (k, N)
+        assert (one.obs == ref.obs).all() and one._epoch == ref._epoch
+        if auto_reset and T >= 7:
+            assert int(one.goal_count.sum().item()) == int(ref.goal_count.sum().item())
+
+
+def test_rollout_other_shapes_run_T_launches_inside_the_library():
+    """Every other shape: lmaze_rollout issues the T step launches itself -- the same results, trajectory rows included."""
+    N, T = 5000, 9
+    one = PKG.LmazeVecEnv(N, variant="v0", layout=PKG.layouts.open_room(11, (5, 5)), seed=2)
+    ref = PKG.LmazeVecEnv(N, variant="v0", layout=PKG.layouts.open_room(11, (5, 5)), seed=2)
+    acts = torch.randint(0, 4, (T, N), dtype=torch.int32, device="cuda")
+    obs, rew, done, rew_t, done_t = one.rollout(acts, auto_reset=True, trajectory=True)
+    for t in range(T):
+        o, r, d, _ = ref.step(acts[t], auto_reset=True)
+        assert (rew_t[t].view(torch.int32) == r.view(torch.int32)).all() and (done_t[t] == d).all()
+    assert (one.obs == ref.obs).all() and (one.ball_xy == ref.ball_xy).all() and one._epoch == ref._epoch
+
+
+# ---------------------------------------------------------------- narrow observation (uint8 planes)
+@pytest.mark.parametrize("variant,G,N", [("v0", 11, 5000), ("v0", 11, 64), ("v3", 11, 777), ("v0", 8, 4096), ("v0", 12, 1025),
+                                         ("v3", 18, 300), ("v0", 5, 1000), ("v0", 4, 33), ("v0", 33, 130), ("v3", 64, 17)])
+def test_u8_observation_is_the_int32_planes_narrowed(variant, G, N):
+    """obs_dtype='u8' (lmaze_step_u8 / lmaze_observe_u8): state and planes equal the int32 mode's on every step, with
+    the fused reset, after masked resets, for even and odd G and ragged batches (a 16-byte store holds 16 cells and
+    straddles envs at every odd G)."""
+    lay = PKG.layouts.open_room(G, (G // 2, G // 2))
+    wide = PKG.LmazeVecEnv(N, variant=variant, layout=lay, seed=21, env_base=7)
+    narrow = PKG.LmazeVecEnv(N, variant=variant, layout=lay, seed=21, env_base=7, obs_dtype="u8")
+    assert narrow.obs.dtype == torch.uint8 and tuple(narrow.obs.shape) == (N, G, G)
+    assert "step_shared_u8_kernel" not in PKG._abi.describe_step(wide.params, N)
+    assert (narrow.obs == wide.obs.to(torch.uint8)).all()                      # reset planes
+    gen = torch.Generator(device="cuda").manual_seed(G * 1000 + N)
+    for t in range(60):
+        a = torch.randint(-1, 6, (N,), dtype=torch.int32, device="cuda", generator=gen)
+        ar = t % 3 != 0
+        ow, rw, dw, _ = wide.step(a, auto_reset=ar)
+        on, rn, dn, _ = narrow.step(a, auto_reset=ar)
+        assert (on == ow.to(torch.uint8)).all(), t
+        assert (rn.view(torch.int32) == rw.view(torch.int32)).all() and (dn == dw).all(), t
+        if t % 17 == 5:                                                         # masked reset: only those planes change
+            m = torch.rand(N, device="cuda", generator=gen) < 0.3
+            wide.reset(mask=m)
+            narrow.reset(mask=m)
+            assert (narrow.obs == wide.obs.to(torch.uint8)).all(), t
+    hw, hn = wide.host_state(), narrow.host_state()
+    for k in hw:
+        assert (np.ascontiguousarray(hw[k]).view(np.uint8) == np.ascontiguousarray(hn[k]).view(np.uint8)).all(), k
+    assert (narrow.expanded() == wide.expanded()).all()
+
+
+def test_u8_observation_at_c3_size_and_refusals():
+    N, G = 1 << 20, 11
+    lay = PKG.layouts.open_room(G, (5, 5))
+    wide = PKG.LmazeVecEnv(N, variant="v0", layout=lay, seed=1)
+    narrow = PKG.LmazeVecEnv(N, variant="v0", layout=lay, seed=1, obs_dtype="u8")
+    acts = torch.randint(0, 4, (12, N), dtype=torch.int32, device="cuda")
+    for t in range(12):
+        wide.step(acts[t], auto_reset=True)
+        narrow.step(acts[t], auto_reset=True)
+    assert (narrow.obs == wide.obs.to(torch.uint8)).all() and (narrow.ball_xy == wide.ball_xy).all()
+    narrow.rollout(acts[:4], auto_reset=True)                                   # T step launches (no one-launch form)
+    wide.rollout(acts[:4], auto_reset=True)
+    assert (narrow.obs == wide.obs.to(torch.uint8)).all() and narrow._epoch == wide._epoch
+    with pytest.raises(ValueError):
+        PKG.LmazeVecEnv(8, variant="v0", per_env_layouts=np.stack([PKG.layouts.to_codes(lay)] * 8), obs_dtype="u8")

@@ -484,9 +484,9 @@ def test_online_tuner_picks_a_policy_without_changing_results():
     fixed = PKG.LmazeVecEnv(N, variant="v0", layout=lay, seed=6)          # opt-in: off unless asked for
     small = PKG.LmazeVecEnv(4096, variant="v0", layout=lay, seed=6, online_autotune=True)
     assert tuned._tuner is not None and fixed._tuner is None and small._tuner is None
-    assert tuned.tuning_progress() == (0, 12 * len(tuned.CANDIDATES)) and fixed.tuning_progress() is None
+    assert tuned.tuning_progress() == (0, 12 * len(tuned.ONLINE_CANDIDATES)) and fixed.tuning_progress() is None
     acts = torch.randint(0, 4, (8, N), dtype=torch.int32, device="cuda")
-    need = tuned._tuner.warm + tuned._tuner.samples * len(tuned.CANDIDATES) + 64
+    need = tuned._tuner.warm + tuned._tuner.samples * len(tuned.ONLINE_CANDIDATES) + 64
     for t in range(need):
         tuned.step(acts[t % 8], auto_reset=True)
         fixed.step(acts[t % 8], auto_reset=True)
@@ -496,7 +496,7 @@ def test_online_tuner_picks_a_policy_without_changing_results():
     for t in range(16):                    # the last pairs are collected on later calls
         tuned.step(acts[t % 8], auto_reset=True)
         fixed.step(acts[t % 8], auto_reset=True)
-    assert tuned._tuner is None and tuned.tuned_policy in tuned.CANDIDATES
+    assert tuned._tuner is None and tuned.tuned_policy in tuned.ONLINE_CANDIDATES
     assert tuned.params.launch_hint == tuned.launch_hint_of(*tuned.tuned_policy)
     assert (tuned.obs == fixed.obs).all() and (tuned._state == fixed._state).all()
     tuned.set_launch_policy(8, 1)

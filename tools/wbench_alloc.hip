@@ -1,5 +1,5 @@
 // wbench_alloc.hip -- developer tool: does the ALLOCATION behind a write target decide the rate of a many-stream write
-// pattern (tools/placement_study3.py)?  Eight separate hipMalloc'ed buffers and eight sub-ranges of one
+// pattern (tools/placement_pmc.py)?  Eight separate hipMalloc'ed buffers and eight sub-ranges of one
 // large allocation, each written with (a) the fill pattern, (b) 32-KiB private chunks per workgroup, uncapped.
 //   hipcc -O3 -std=c++17 --offload-arch=gfx950 tools/wbench_alloc.hip -o tools/wbench_alloc && ./tools/wbench_alloc
 #include <hip/hip_runtime.h>
