@@ -24,8 +24,10 @@
 // counts): 1 no set-up, 2 plain instead of non-temporal observation stores, 4 no observation stores, 8 no phase 1,
 // 16 stores as interleaved 4-KiB pieces, 32 no visit-map phase, 64 / 128 non-temporal visit-map stores / loads.
 #ifdef LMAZE_EXPERIMENT
+#define LMAZE_WARM_V4(args) ((((args).p.launch_hint >> 16) & 1024) != 0)
 #define LMAZE_XP(args, mask) ((((args).p.launch_hint >> 16) & (mask)) != 0)   // round 3: 256 no per-cell work on gathered tiles, 512 no "previous" window tiles
 #else
+#define LMAZE_WARM_V4(args) false
 #define LMAZE_XP(args, mask) false
 #endif
 
@@ -257,10 +259,17 @@ __global__ __launch_bounds__(LMAZE_BLOCK) LMAZE_FOVEAL_ATTR void foveal_kernel(c
     int warmed = 0;
     if (MODE == FM_STEP && a.nt) {
         warmed = warm_lines(a.action, a.n * 4, 256);
-        if (!V4) {   // v1, v2: the per-env state as well (v2 -3 %); v4's read stream is the visit maps, and there it costs 5-10 %
+        // v1, v2: the per-env state as well (v2 -3 %).  v4 since its visit map is window-only (round 3: 334-338 us against
+        // 341-377 without, three interleaved passes); v5/v6: no gain (418-443 against 425-465) -- experiment switch only
+        if (!V5 || LMAZE_WARM_V4(a)) {
             warmed += warm_lines(a.b.ball_xy, a.n * 8, 256) + warm_lines(a.b.step_count, a.n * 4, 256);
             if (V1) warmed += warm_lines(a.b.fgoal_xy, a.n * 8, 256) + warm_lines(a.b.foveal_step_count, a.n * 4, 256);
             else warmed += warm_lines(a.b.goal_xy, a.n * 8, 256) + warm_lines(a.b.layout_id, a.n * 4, 256);
+            if (V4) warmed += warm_lines(a.b.visit_clock, a.n * 4, 256);
+            if (V5) warmed += warm_lines(a.b.fgoal_xy, a.n * 8, 256) + warm_lines(a.b.foveal_step_count, a.n * 4, 256) +
+                              warm_lines(a.b.fovea_xy, a.n * 16, 256) + warm_lines(a.b.ball1_xy, a.n * 8, 256) +
+                              warm_lines(a.b.last_xy, a.n * 8, 256) + warm_lines(a.b.foveal_goal, a.n * 4, 256) +
+                              warm_lines(a.goal2, a.n * 4, 256);
         }
     }
     if (LMAZE_XP(a, 1)) {
@@ -357,6 +366,13 @@ __global__ __launch_bounds__(LMAZE_BLOCK) LMAZE_FOVEAL_ATTR void foveal_kernel(c
         bool last_is_cur = true;              // v5/v6: the window shown as "previous" from now on is this call's current one
         int rx = 0, ry = 0;                   // ball the fused reset placed
         int bx = a.b.ball_xy[2 * e], by = a.b.ball_xy[2 * e + 1];
+        // every per-env input of a step is requested HERE, before anything is branched on: a load that sits behind a branch
+        // on another loaded value (the done flag of the fused reset, localDone of the two-level step) is a second global
+        // round trip in series -- v4's fused reset cost +58...95 us per launch that way (round 3, tools/_ar_study)
+        const int act_in = (MODE == FM_STEP) ? a.action[e] : 0;
+        const int sc_ld = (MODE == FM_STEP) ? a.b.step_count[e] : 0;
+        const int done_in = (MODE == FM_STEP && AR) ? a.b.done[e] : 0;
+        const int goal2_in = (MODE == FM_STEP && AR && V5) ? a.goal2[e] : 0;
         const int vword = (V4 && !(V5 && MODE == FM_PLANNER)) ? a.b.visit_clock[e] : 0;
         const int vclock = vword & 0xff;
         r.px = (int16_t)bx; r.py = (int16_t)by;
@@ -365,13 +381,13 @@ __global__ __launch_bounds__(LMAZE_BLOCK) LMAZE_FOVEAL_ATTR void foveal_kernel(c
             int fgx = a.b.fgoal_xy[2 * e], fgy = a.b.fgoal_xy[2 * e + 1];
             r.action = 1;  // local view unless this is a reset
             if (MODE == FM_STEP) {
-                int sc_in = a.b.step_count[e];
-                if (AR && a.b.done[e]) {                     // fused reset(): v1:82-93
+                int sc_in = sc_ld;
+                if (AR && done_in) {                         // fused reset(): v1:82-93
                     for (int c = 0; c < CELLS; ++c)
                         if (lays[c] == 'S') { bx = c / G; by = c % G; break; }
                     sc_in = 0;
                 }
-                const int act = a.action[e];
+                const int act = act_in;
                 const int sc = sc_in + 1;                              // v1:117
                 const int fsc = a.b.foveal_step_count[e] + 1;          // v1:118
                 float fr = -0.0f, rw = -0.0f;                          // v1:120-121
@@ -430,10 +446,10 @@ __global__ __launch_bounds__(LMAZE_BLOCK) LMAZE_FOVEAL_ATTR void foveal_kernel(c
             int b1x = a.b.ball1_xy[2 * e], b1y = a.b.ball1_xy[2 * e + 1];
             int lx = a.b.last_xy[2 * e], ly = a.b.last_xy[2 * e + 1];
             if (MODE == FM_STEP) {                                     // v5:187-292
-                const int act = a.action[e];
+                const int act = act_in;
                 int fgx = a.b.fgoal_xy[2 * e], fgy = a.b.fgoal_xy[2 * e + 1];
                 int fsc = a.b.foveal_step_count[e];
-                int sc_in = a.b.step_count[e];
+                int sc_in = sc_ld;
                 bool ld = a.b.foveal_done[e] != 0, gd = a.b.done[e] != 0;   // both persist across step() calls
                 if (AR) {
                     // the two-level loop around step() (lmaze_v5_hier_step): reset() for an env that enters with
@@ -455,7 +471,7 @@ __global__ __launch_bounds__(LMAZE_BLOCK) LMAZE_FOVEAL_ATTR void foveal_kernel(c
                         fresh = true;
                     }
                     if (plan) {                                        // plannerStep(goal): v5:158-182, as FM_PLANNER below
-                        const int g = a.goal2[e];
+                        const int g = goal2_in;
                         if (g >= 0 && g < W25) {
                             fg = g;
                             sc_in = 0;                                 // v5:160
@@ -565,7 +581,7 @@ __global__ __launch_bounds__(LMAZE_BLOCK) LMAZE_FOVEAL_ATTR void foveal_kernel(c
             int lid = a.b.layout_id[e];
             int gx = a.b.goal_xy[2 * e], gy = a.b.goal_xy[2 * e + 1];
             int sc_in = 0;
-            const bool fused = MODE == FM_STEP && AR && a.b.done[e] != 0;
+            const bool fused = MODE == FM_STEP && AR && done_in != 0;
             if ((MODE == FM_RESET && !r.skip) || fused) {              // reset(): v2:80-123, v4:95-163
                 if (a.place || fused) {
                     const uint4 d = env_draw(a.seed, epoch, a.env_base + e);
@@ -592,10 +608,10 @@ __global__ __launch_bounds__(LMAZE_BLOCK) LMAZE_FOVEAL_ATTR void foveal_kernel(c
                 fresh = true;
                 rx = bx; ry = by;
             } else if (MODE == FM_STEP) {
-                sc_in = a.b.step_count[e];
+                sc_in = sc_ld;
             }
             if (MODE == FM_STEP) {
-                const int act = a.action[e];
+                const int act = act_in;
                 if (act < 0 || act >= W25) {
                     if (fresh) nostep = true;                          // reset, then the reference's step() raises
                     else r.skip = 1;                                   // the reference raises before touching anything
@@ -1231,7 +1247,6 @@ static hipError_t launch_foveal_one(const FovealArgs& a, hipStream_t s) {
 // launch_hint bits 4-7 (plain step only): envs per workgroup, 2: 32 ... 5: 256; anything else = the default below
 template <int VARIANT>
 static bool launch_step_hinted(const FovealArgs& a, hipStream_t s, hipError_t& rc) {
-    if (a.auto_reset && VARIANT != LMAZE_VARIANT_V5) return false;   // v1/v2/v4 fused reset: one measured size each (below)
     switch ((a.p.launch_hint >> 4) & 15) {
         case 2: rc = launch_foveal_one<VARIANT, FM_STEP, 32>(a, s); return true;
         case 3: rc = launch_foveal_one<VARIANT, FM_STEP, 64>(a, s); return true;
@@ -1266,8 +1281,10 @@ static hipError_t launch_foveal_mode(const FovealArgs& a0, hipStream_t s) {
     if (MODE == FM_STEP && a.p.launch_hint == 0 && a.auto_reset && (size_t)a.n * W25 * 4 * 4 > kFovealStreamBytes) {
         // fused reset (v1, v2, v4; one measured size each, below), same sweeps: v1 at 5 workgroups per CU 74.0 / 74.0 us
         // against 74.2 / 76.8 uncapped; v2 two chunks 97.3 / 99.2 against 102.9 / 100.2; v4 two chunks 402-406 against 426-430
-        if (a.p.variant == LMAZE_VARIANT_V1) a.p.launch_hint = 0x05;
-        else if (a.p.variant == LMAZE_VARIANT_V2 || a.p.variant == LMAZE_VARIANT_V4) a.p.launch_hint = 0x100;
+        // (foveal_sweep_ar_a.jsonl, once the envs-per-workgroup hints applied to the fused reset too: v4 128 envs 377-378 us
+        // against 417 at 64 envs x 2 chunks; v2 128 x 2 97.3 against 99.3; v1 64 envs at 4-5 per CU 72.9-73.0 against 74.0)
+        if (a.p.variant == LMAZE_VARIANT_V1) a.p.launch_hint = 0x35;
+        else if (a.p.variant == LMAZE_VARIANT_V2 || a.p.variant == LMAZE_VARIANT_V4) a.p.launch_hint = 0x140;
     }
     if (MODE == FM_STEP) {
         hipError_t rc = hipSuccess;
