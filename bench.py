@@ -651,6 +651,9 @@ def main():
                          # the untuned library: first allocation AND launch_hint 0 (the per-shape default of the policy table)
                          "frac_untuned_library": (N * B / (pl["first_ms_default"] * 1e-3) / 1e9 / HBM_PEAK_GBS
                                                   if pl and pl.get("first_ms_default") else None),
+                         "note": ("on-die: the planes of this batch never leave L2 / the Infinity Cache, so the HBM fraction is "
+                                  "nominal (it can exceed 1)" if args.one_launch else
+                                  "frac is priced on algorithmic bytes; traffic is what the PMC counters saw for this launch shape"),
                          "clock": "achieved / frac: ms_per_step (perf_counter around the timed launches, max over ranks); "
                                   "achieved_events / frac_events / kernel_ms_avg: HIP events on rank 0's launch stream",
                          "measured_ceiling": ceiling},
