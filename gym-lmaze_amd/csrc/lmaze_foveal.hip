@@ -715,19 +715,12 @@ __global__ __launch_bounds__(LMAZE_BLOCK) LMAZE_FOVEAL_ATTR void foveal_kernel(c
 
     // ---------------- phase 2 (v4-v6): the visit maps, v4:116-119 / v4:211-214 / v5:313-318 ----------------
     // Clock-relative tiles (include/lmaze.h "The visit map"): the whole-plane halving already happened in phase 1 (the
-    // env's clock moved); what is left is the 5x5 window, ONE CELL PER LANE, registers only:
-    //   pass 1  lane (env, window 0: current / 1: "previous", cell 0..24) loads its cell -- from the env's tiles (the
-    //           current window always covers exactly 2 x 2 of them: 3 memory lines on average) or, v5/v6, from the
-    //           env's "previous window" record (112 contiguous bytes) when that window lies elsewhere; every load of 64
-    //           envs is in flight before the first is used;
-    //   pass 2  (after a barrier: no cell is stored before every lane that shows it has loaded it) a cell inside the
-    //           current window takes (v + 1) / 2 when the map updates this call and goes back re-encoded under the new
-    //           clock -- a 4-byte store into a line the load has just brought into L2 --, and the TRUE values both
-    //           windows show (the previous one sampled live from the updated map, Appendix B-7) are left in vwin.
-    // The few envs whose whole map is rewritten (reset: zeros; clock at VISIT_RENORM: true values) are streamed tile by
-    // tile.  (Tried and dropped this round: whole tiles through registers, 16 B per lane -- the per-row bookkeeping made
-    // the phase issue-bound, 130 of 440 us --, and whole tiles staged in LDS by LDS-DMA -- 640 B of LDS per env left 3
-    // workgroups per CU.)
+    // env's clock moved); what is left is the 5x5 window.  The few envs whose whole map is rewritten (reset: zeros; clock at
+    // VISIT_RENORM: true values) are streamed tile by tile; everybody else goes through the window pass below, one lane per
+    // window row.  (Tried and dropped this round, LAB_NOTES.md R3.1 / R3.5: one lane per TILE row -- the bookkeeping made the
+    // phase issue-bound --, whole tiles staged in LDS by LDS-DMA -- 640 B of LDS per env --, one wave instruction per env, and
+    // a software-pipelined chunk loop that issues the next chunk's phase 1 and tile loads before this chunk's stores --
+    // 45 registers of loads held across the store phase: 171-214 VGPRs, 2-3 waves per SIMD, 357 / 552 us against 296 / 422.)
     if (V4 && !(V5 && MODE == FM_PLANNER) && !LMAZE_XP(a, 32)) {
         const int TB = visit_tiles(G), TILES = TB * TB;
         uint32_t* vis = reinterpret_cast<uint32_t*>(a.b.visit) + (size_t)blockbase * TILES * (VT * VT);
