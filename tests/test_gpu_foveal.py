@@ -804,3 +804,106 @@ def test_dropin_v5_batched_hier_step_is_the_three_calls():
             assert (x.view(torch.uint8) == y.view(torch.uint8)).all() if x.dtype != torch.bool else (x == y).all(), t
     with pytest.raises(ValueError):
         PKG.LmazeEnv_v5().hierStep(0, 0)
+
+
+# ---------------------------------------------------------------- other grid sizes (tile geometry of the visit map)
+def _padded_layouts(G, count, seed):
+    """`count` random mazes of side G with the 4-cell 'W' padding the teleporting variants need (lmaze_env_v2.py:309-326),
+    one 'S' and one 'X' each."""
+    rs = np.random.RandomState(seed)
+    out = []
+    for _ in range(count):
+        g = np.full((G, G), ord("W"), np.uint8)
+        inner = np.where(rs.rand(G - 8, G - 8) < 0.2, ord("W"), ord("B")).astype(np.uint8)
+        inner[0, 0], inner[-1, -1] = ord("S"), ord("X")
+        g[4:-4, 4:-4] = inner
+        out.append(g)
+    return out
+
+
+@pytest.mark.parametrize("variant,G", [("v4", 13), ("v4", 14), ("v4", 21), ("v5", 13), ("v5", 20), ("v5", 33)])
+def test_visit_map_on_other_grid_sizes(variant, G):
+    """G that is not 18 and not a multiple of the 4x4 tile: the unspecialised kernel, padded tiles, window rows that start in
+    any column phase -- every step against the oracle's dense plane (materialised visit map, both observations), with
+    resets, for v4's step and v5's two-level step."""
+    N, seed = 700, 40 + G
+    lays = _padded_layouts(G, 3, seed)
+    env = PKG.LmazeFovealVecEnv(N, variant=variant, layouts=lays, seed=seed, env_base=2)
+    lay = _np(env.layouts)
+    rs = np.random.RandomState(G)
+    if variant == "v4":
+        p = O.foveal_params(O.VARIANT_V4, G, 3)
+        st = O.FovealState(O.VARIANT_V4, N, G)
+        O.foveal_reset(p, lay, None, 1, seed, 0, st, env_base=2)
+        _assert_same(env, st, "v4", "reset")
+        for t in range(90):
+            a = rs.randint(0, 25, N).astype(np.int32)
+            m = st.done.copy()
+            epoch = env._epoch
+            env.step(torch.from_numpy(a), auto_reset=True)
+            O.foveal_reset(p, lay, m, 1, seed, epoch, st, env_base=2)
+            O.foveal_step(p, lay, a, st)
+            _assert_same(env, st, "v4", t)
+    else:
+        p = O.foveal_params(O.VARIANT_V5, G, 3)
+        st = O.FovealState(O.VARIANT_V5, N, G)
+        O.v5_reset(p, lay, None, 1, seed, 0, st, env_base=2)
+        env.foveal_done.fill_(True)
+        st.foveal_done[:] = 1
+        st.obs_local[...] = _np(env.obs_local)
+        for t in range(120):
+            a, g = rs.randint(0, 4, N).astype(np.int32), rs.randint(0, 25, N).astype(np.int32)
+            epoch = env._epoch
+            env.hier_step(torch.from_numpy(a), torch.from_numpy(g))
+            O.v5_hier_step(p, lay, a, g, seed, epoch, st, env_base=2)
+            _same56(env, st, t)
+
+
+def test_load_visit_takes_the_references_plane_mid_rollout():
+    """lmaze_foveal_load_visit: the reference's own state[2] (v4_deepdecay fixture, cells below 2^-126 included) injected in
+    the middle of the walk; the steps that follow match the recording, whole plane included."""
+    g = load_golden("v4_deepdecay_seed9")
+    for t0 in (150, 480, 900):
+        env = PKG.LmazeFovealVecEnv(1, variant="v4", layouts=list(g["layouts"]))
+        env.set_state(ball_xy=g["ball"][t0:t0 + 1], goal_xy=g["goal_before"][t0 + 1:t0 + 2], layout_id=g["layout_id"][t0 + 1:t0 + 2],
+                      step_count=g["step_count"][t0:t0 + 1])
+        env.load_visit(g["visit"][t0:t0 + 1])
+        assert (_bits(_np(env.visit)[0]) == _bits(g["visit"][t0])).all()
+        for t in range(t0 + 1, t0 + 80):
+            obs, _, _, _ = env.step(g["actions"][t:t + 1])
+            assert (_bits(_np(obs)[0]) == _bits(g["planes"][t])).all(), (t0, t)
+            assert (_bits(_np(env.visit)[0]) == _bits(g["visit"][t])).all(), (t0, t)
+
+
+@pytest.mark.parametrize("variant", ["v4", "v5"])
+def test_materialise_then_load_visit_is_invisible(variant):
+    """visit -> lmaze_foveal_materialise_visit -> lmaze_foveal_load_visit re-encodes every map in the true-value frame and drops
+    the "previous window" records (v5/v6 then read that window from the tiles once): a twin that never made the round trip
+    produces the same bits from then on."""
+    N = 3000
+    a_env, b_env = (PKG.LmazeFovealVecEnv(N, variant=variant, seed=17) for _ in range(2))
+    gen = torch.Generator(device="cuda").manual_seed(3)
+    hi = 4 if variant == "v5" else 25
+    for e in (a_env, b_env):
+        if variant == "v5":
+            e.foveal_done.fill_(True)
+
+    def step(e, a, gl):
+        if variant == "v5":
+            e.hier_step(a, gl)
+        else:
+            e.step(a, auto_reset=True)
+
+    for t in range(140):
+        a = torch.randint(0, hi, (N,), dtype=torch.int32, device="cuda", generator=gen)
+        gl = torch.randint(0, 25, (N,), dtype=torch.int32, device="cuda", generator=gen)
+        if t in (37, 90):
+            b_env.load_visit(b_env.visit)
+        step(a_env, a, gl)
+        step(b_env, a, gl)
+        assert (_bits(_np(a_env.obs)) == _bits(_np(b_env.obs))).all(), t
+        if t % 20 == 0 or t in (37, 38, 90, 91):
+            assert (_bits(_np(a_env.visit)) == _bits(_np(b_env.visit))).all(), t
+            if a_env.obs_local is not None:
+                assert (_bits(_np(a_env.obs_local)) == _bits(_np(b_env.obs_local))).all(), t
+    assert (a_env._state == b_env._state).all()
