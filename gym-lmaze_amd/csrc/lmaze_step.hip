@@ -782,6 +782,14 @@ __global__ __launch_bounds__(LMAZE_BLOCK) void step_shared_u8_kernel(const StepA
     if (autoreset) pass_epoch_on(a.epoch_in, a.epoch_out);
     EnvIn in{};
     if (tid < nb) in = load_env<VARIANT, DO_STEP>(a, blockbase + tid);
+    // large batches: the first 256 workgroups touch every line of this step's per-env inputs once, as step_shared_kernel does
+    int warmed = 0;
+    if (DO_STEP && (a.launch_hint & 0x100)) {
+        warmed = warm_lines(a.action, a.n * 4, 256) + warm_lines(a.ball, a.n * 8, 256) + warm_lines(a.step_count, a.n * 4, 256);
+        if (!V3) warmed += warm_lines(a.reward, a.n * 4, 256);
+        if (V3) warmed += warm_lines(a.goal, a.n * 8, 256);
+        if (autoreset) warmed += warm_lines(a.done, a.n, 256);
+    }
     // set-up: ONE global round trip (the layout bytes, beside the env loads above), then everything from LDS
     for (int i = tid; i < CELLS; i += LMAZE_BLOCK) lay[i] = a.layout[i];
     __syncthreads();
@@ -877,6 +885,7 @@ __global__ __launch_bounds__(LMAZE_BLOCK) void step_shared_u8_kernel(const StepA
     nb = nb_next;
     in = in_next;
   }
+    if (warmed == 0x7fedcba9 && a.n < 0) a.done[0] = 1;   // never true: keeps the warming loads alive
 }
 
 // ------------------------------------------------------------------------------------
