@@ -73,61 +73,59 @@ struct EnvRec {           // one env after its transition (registers only; phase
 
 // Placement on row masks.  rows[x] has bit y set when interior cell (x, y) is accepted; accepted cells are
 // ranked in row-major order (the order of the reference's own scan over the grid).
-__device__ __forceinline__ int mask_count(const uint64_t* rows, int G) {
-    int cnt = 0;
-    // not unrolled: with G known at compile time the unrolled loops keep a whole layout's row masks live and
-    // the fused-reset instantiation then needs 115 VGPRs (4 waves per SIMD instead of 7) for the whole kernel
-#pragma unroll 1
-    for (int x = 1; x <= G - 2; ++x) cnt += __popcll(rows[x]);
-    return cnt;
+
+// accepted cells of the goal and of the ball mask, one pass.  Unrolled by 4 and no more: the loop is a chain of LDS round
+// trips in a lane that a whole wave waits for (some lane of most waves resets at steady state), so it wants several
+// reads in flight, but with G known at compile time a FULL unroll keeps a layout's row masks live and the fused-reset
+// instantiation then needs 115 VGPRs (4 waves per SIMD instead of 7) for the whole kernel
+template <int U>
+__device__ __forceinline__ void mask_counts(const uint64_t* goal_rows, const uint64_t* ball_rows, int G, int& cg, int& cb) {
+    cg = 0; cb = 0;
+#pragma unroll(U)
+    for (int x = 1; x <= G - 2; ++x) { cg += __popcll(goal_rows[x]); cb += __popcll(ball_rows[x]); }
 }
 
-// rank of cell (gx, gy) among the accepted cells (number of accepted cells before it)
-__device__ __forceinline__ int mask_rank(const uint64_t* rows, int G, int gx, int gy) {
-    int cnt = 0;
-#pragma unroll 1
-    for (int x = 1; x < gx && x <= G - 2; ++x) cnt += __popcll(rows[x]);
-    if (gx >= 1 && gx <= G - 2) cnt += __popcll(rows[gx] & ((1ull << gy) - 1ull));
-    return cnt;
-}
-
-// k-th accepted cell (0-based) as x*G + y, or -1
-__device__ __forceinline__ int mask_kth(const uint64_t* rows, int G, int k) {
-#pragma unroll 1
+// k-th accepted cell (0-based) as x*G + y, or -1, of the mask with cell `hole` (x*G + y; negative: none) taken out.
+// No early exit, so that the row reads pipeline (see mask_counts).  The hole is tested as "hole - x*G in [0, G)" so that
+// nothing but the cell index itself stays live across the loop.
+template <int U>
+__device__ __forceinline__ int mask_kth(const uint64_t* rows, int G, int k, int hole) {
+    int xr = -1, kk = 0, acc = 0;
+#pragma unroll(U)
     for (int x = 1; x <= G - 2; ++x) {
         uint64_t m = rows[x];
+        const unsigned hy = (unsigned)(hole - x * G);
+        if (hy < (unsigned)G) m &= ~(1ull << hy);
         const int c = __popcll(m);
-        if (k < c) {
-            for (; k > 0; --k) m &= m - 1;
-            return x * G + (__ffsll((long long)m) - 1);
-        }
-        k -= c;
+        if (xr < 0 && k < acc + c) { xr = x; kk = k - acc; }
+        acc += c;
     }
-    return -1;
+    if (xr < 0) return -1;
+    uint64_t m = rows[xr];
+    const unsigned hy = (unsigned)(hole - xr * G);
+    if (hy < (unsigned)G) m &= ~(1ull << hy);
+    uint32_t h = (uint32_t)m;
+    int base = 0;
+    const int cl = __popc(h);
+    if (kk >= cl) { kk -= cl; h = (uint32_t)(m >> 32); base = 32; }
+    for (; kk > 0; --kk) h &= h - 1;
+    return xr * G + base + (__ffs((int)h) - 1);
 }
 
 // reset() placement of v2/v4/v5/v6 on one layout (v2:277-296): goal uniform over interior cells that are
-// not 'W' and not 'S'; ball uniform over interior cells that are not 'W', not 'X' and not the goal
+// not 'W' and not 'S'; ball uniform over interior cells that are not 'W', not 'X' and not the goal.  Accepted cells
+// are ranked row-major (the order of the reference's own scan); "not the goal" = the goal's bit taken out of the
+// ball mask, which leaves the ranking of every other cell as the reference's list has it.
+template <int U>
 __device__ __forceinline__ void place_goal_ball(const uint64_t* goal_rows, const uint64_t* ball_rows, int G, uint4 d,
                                                 int& goal_cell, int& ball_cell) {
     goal_cell = -1;
     ball_cell = -1;
-    const int cg = mask_count(goal_rows, G);
-    if (cg > 0) goal_cell = mask_kth(goal_rows, G, (int)__umulhi(d.x, (uint32_t)cg));
-    int cb = mask_count(ball_rows, G);
-    int skip_rank = -1;   // the goal's rank in the ball list when it is in it (a 'B' goal cell)
-    if (goal_cell >= 0) {
-        const int gx = goal_cell / G, gy = goal_cell % G;
-        if ((ball_rows[gx] >> gy) & 1ull) {
-            skip_rank = mask_rank(ball_rows, G, gx, gy);
-            --cb;
-        }
-    }
-    if (cb > 0) {
-        int kb = (int)__umulhi(d.y, (uint32_t)cb);
-        if (skip_rank >= 0 && kb >= skip_rank) ++kb;
-        ball_cell = mask_kth(ball_rows, G, kb);
-    }
+    int cg, cb;
+    mask_counts<U>(goal_rows, ball_rows, G, cg, cb);
+    if (cg > 0) goal_cell = mask_kth<U>(goal_rows, G, (int)__umulhi(d.x, (uint32_t)cg), -1);
+    if (goal_cell >= 0 && ((ball_rows[goal_cell / G] >> (goal_cell % G)) & 1ull)) --cb;   // a 'B' goal cell leaves the ball's list
+    if (cb > 0) ball_cell = mask_kth<U>(ball_rows, G, (int)__umulhi(d.y, (uint32_t)cb), goal_cell);
 }
 
 // numpy index semantics on an axis of 5: -5..-1 wrap, anything else outside 0..4 raises (-> -1)
@@ -214,6 +212,9 @@ __global__ __launch_bounds__(LMAZE_BLOCK) LMAZE_FOVEAL_ATTR void foveal_kernel(c
     constexpr bool V1 = VARIANT == LMAZE_VARIANT_V1, V5 = VARIANT == LMAZE_VARIANT_V5;
     constexpr bool V4 = VARIANT == LMAZE_VARIANT_V4 || V5;   // "has a visit map"
     constexpr int C = V1 ? 4 : (V4 ? 7 : 5);
+    // reset placement: row reads in flight per pass (mask_counts).  The two-level variants sit at the 128-VGPR step
+    // (4 waves per SIMD) and any unrolling there costs a wave; v2/v4 have the room
+    constexpr int PLACE_U = V5 ? 1 : 4;
     constexpr int PERENV = C * W25;  // floats of observation per env
     const int G = GT ? GT : a.p.grid, CELLS = G * G, L = V1 ? 1 : a.p.n_layouts;
 
@@ -460,7 +461,7 @@ __global__ __launch_bounds__(LMAZE_BLOCK) LMAZE_FOVEAL_ATTR void foveal_kernel(c
                         const uint4 d = env_draw(a.seed, epoch, a.env_base + e);
                         lid = (int)__umulhi(d.z, (uint32_t)L);         // v5:105 setGrid first
                         int goal_cell, ball_cell;
-                        place_goal_ball(rowgoal + lid * G, rowball + lid * G, G, d, goal_cell, ball_cell);
+                        place_goal_ball<PLACE_U>(rowgoal + lid * G, rowball + lid * G, G, d, goal_cell, ball_cell);
                         if (goal_cell >= 0) { gx = goal_cell / G; gy = goal_cell % G; }
                         if (ball_cell >= 0) { bx = ball_cell / G; by = ball_cell % G; }
                         a.b.layout_id[e] = lid;
@@ -548,7 +549,7 @@ __global__ __launch_bounds__(LMAZE_BLOCK) LMAZE_FOVEAL_ATTR void foveal_kernel(c
                     lid = (int)__umulhi(d.z, (uint32_t)L);             // v5:105 setGrid first
                     a.b.layout_id[e] = lid;
                     int goal_cell, ball_cell;
-                    place_goal_ball(rowgoal + lid * G, rowball + lid * G, G, d, goal_cell, ball_cell);
+                    place_goal_ball<PLACE_U>(rowgoal + lid * G, rowball + lid * G, G, d, goal_cell, ball_cell);
                     if (goal_cell >= 0) {
                         gx = goal_cell / G; gy = goal_cell % G;
                         a.b.goal_xy[2 * e] = gx; a.b.goal_xy[2 * e + 1] = gy;
@@ -589,7 +590,7 @@ __global__ __launch_bounds__(LMAZE_BLOCK) LMAZE_FOVEAL_ATTR void foveal_kernel(c
                     if (V4) lid = lid_new;                             // v4:97 setGrid first
                     lid = clampi(lid, 0, L - 1);
                     int goal_cell, ball_cell;
-                    place_goal_ball(rowgoal + lid * G, rowball + lid * G, G, d, goal_cell, ball_cell);
+                    place_goal_ball<PLACE_U>(rowgoal + lid * G, rowball + lid * G, G, d, goal_cell, ball_cell);
                     if (goal_cell >= 0) {
                         gx = goal_cell / G; gy = goal_cell % G;
                         a.b.goal_xy[2 * e] = gx; a.b.goal_xy[2 * e + 1] = gy;
