@@ -606,7 +606,8 @@ def main():
             kernel = "lmaze::" + abi.describe_step(env.params, N, auto_reset=bool(args.auto_reset),
                                                    with_obs="u8" if args.obs_dtype == "u8" else True)
             if args.one_launch:
-                kernel += " -- timed as ONE lmaze_rollout call of %d steps (rollout_shared_wave8_kernel where the planes stay on-die)" % args.steps
+                kernel += (" -- timed as ONE lmaze_rollout call of %d steps (rollout_shared_wave8_kernel at 8x8, rollout_shared_kernel "
+                           "at other grids, where the planes stay on-die)" % args.steps)
             perenv_kernel = None
             if args.per_env_layouts:
                 # BASELINE config 5 names an LDS-tiled maze per workgroup; at G*G a multiple of 256 the register-tiled

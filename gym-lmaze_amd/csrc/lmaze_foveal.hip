@@ -81,7 +81,7 @@ struct EnvRec {           // one env after its transition (registers only; phase
 template <int U>
 __device__ __forceinline__ void mask_counts(const uint64_t* goal_rows, const uint64_t* ball_rows, int G, int& cg, int& cb) {
     cg = 0; cb = 0;
-#pragma unroll(U)
+#pragma unroll U
     for (int x = 1; x <= G - 2; ++x) { cg += __popcll(goal_rows[x]); cb += __popcll(ball_rows[x]); }
 }
 
@@ -91,7 +91,7 @@ __device__ __forceinline__ void mask_counts(const uint64_t* goal_rows, const uin
 template <int U>
 __device__ __forceinline__ int mask_kth(const uint64_t* rows, int G, int k, int hole) {
     int xr = -1, kk = 0, acc = 0;
-#pragma unroll(U)
+#pragma unroll U
     for (int x = 1; x <= G - 2; ++x) {
         uint64_t m = rows[x];
         const unsigned hy = (unsigned)(hole - x * G);

@@ -999,6 +999,121 @@ __global__ __launch_bounds__(LMAZE_BLOCK) void rollout_shared_wave8_kernel(const
     }
 }
 
+// T steps of a shared-layout batch of ANY grid size in one launch, for batches whose planes stay on-die: a workgroup owns
+// EPB envs for the whole rollout -- one lane per env keeps ball, goal, stepCount, reward and done in registers across the
+// T steps, the layout, its plane pattern and the spawn list are set up in LDS once -- and re-renders its envs' planes after
+// every step exactly as T launches of step_shared_kernel would (two barriers per step, no grid-wide one: envs are
+// independent).  Per-step launches of such a batch are launch-bound (65 536 x 11x11: 8 us per launch for 32 MB of planes
+// that never leave the caches).  Transition, fused reset (placement from the compacted spawn list with the draw of
+// epoch + t) and the v0 reward persistence are the step kernel's own functions: bit-identical by construction and by test.
+template <int VARIANT>
+__global__ __launch_bounds__(LMAZE_BLOCK) void rollout_shared_kernel(const StepArgs a, const RolloutArgs ro) {
+    constexpr bool V3 = VARIANT == LMAZE_VARIANT_V3;
+    const int G = a.grid, CELLS = G * G, EPB = a.envs_per_block;
+    extern __shared__ int4 lds4[];
+    int* pat = reinterpret_cast<int*>(lds4);                                  // [CELLS] plane bits without ball / goal
+    int* ballflat = pat + CELLS;                                              // [EPB]
+    int* goalflat = ballflat + EPB;                                           // [EPB]
+    uint8_t* lay = reinterpret_cast<uint8_t*>(goalflat + EPB);                // [CELLS]
+    uint16_t* spawn = reinterpret_cast<uint16_t*>(lay + ((CELLS + 15) & ~15));   // [CELLS] accepted spawn cells, row-major
+    __shared__ int spawn_count_s;
+
+    const int tid = threadIdx.x;
+    const int64_t blockbase = (int64_t)blockIdx.x * EPB;
+    const int nb = (int)min((int64_t)EPB, a.n - blockbase);
+    const bool autoreset = a.auto_reset != 0, live = tid < nb;
+    const int64_t e = blockbase + tid;
+    int2 b = make_int2(1, 1), g = make_int2(-1, -1);
+    int sc = 0, was_done = 0, hits = 0, act_next = -1;
+    float r = 0.0f;
+    if (live) {                                                               // in flight over the set-up
+        b = a.ball[e];
+        if (V3) g = a.goal[e];
+        sc = a.step_count[e];
+        if (!V3) r = a.reward[e];
+        if (autoreset) was_done = a.done[e];
+        act_next = ro.actions[e];
+    }
+    for (int i = tid; i < CELLS; i += LMAZE_BLOCK) {
+        const uint8_t c = a.layout[i];
+        lay[i] = c;
+        pat[i] = cell_bits<VARIANT>(c);
+    }
+    if (autoreset && tid < 64) {
+        const int cnt = wave_build_spawn_list<VARIANT>(a.layout, G, CELLS, spawn, tid);
+        if (tid == 0) spawn_count_s = cnt;
+    }
+    __syncthreads();
+    const int spawn_count = autoreset ? spawn_count_s : 0;
+
+    int32_t* obs = a.obs ? a.obs + (size_t)blockbase * CELLS : nullptr;
+    const int R = nb * CELLS, nq = R >> 2;
+    bool dn = false;
+    for (int t = 0; t < ro.T; ++t) {
+        if (live) {
+            const int act = act_next;
+            if (t + 1 < ro.T) act_next = ro.actions[(size_t)(t + 1) * a.n + e];       // next step's row, in flight over this step
+            float r_in = r;
+            if (autoreset && was_done) {                                              // reference reset(), as env_phase1
+                int bc, gc;
+                place_from_list<VARIANT>(spawn, spawn_count, env_draw(a.seed, a.epoch + (uint64_t)t, a.env_base + e), bc, gc);
+                if (bc >= 0) b = make_int2(bc / G, bc % G);
+                if (V3 && gc >= 0) g = make_int2(gc / G, gc % G);
+                sc = 0;         // v0:110
+                r_in = -0.0f;   // v0:109
+            }
+            int bx = clampi(b.x, 0, G - 1), by = clampi(b.y, 0, G - 1);
+            sc += 1;            // v0:151, v3:225
+            int ox, oy;
+            decode_action(act, ox, oy);
+            const int tx = clampi(bx + ox, 0, G - 1), ty = clampi(by + oy, 0, G - 1);
+            hits += transition_rule<VARIANT>(a, lay[tx * G + ty], ox, oy, tx, ty, sc, r_in, g.x, g.y, bx, by, r, dn) ? 1 : 0;
+            b = make_int2(bx, by);
+            was_done = dn ? 1 : 0;
+            if (ro.reward_t) ro.reward_t[(size_t)t * a.n + e] = r;
+            if (ro.done_t) ro.done_t[(size_t)t * a.n + e] = dn ? 1 : 0;
+            ballflat[tid] = b.x * G + b.y;
+            if (V3) goalflat[tid] = (g.x >= 0 && g.x < G && g.y >= 0 && g.y < G) ? g.x * G + g.y : -8;
+        }
+        if (obs == nullptr) continue;                                                 // uniform
+        __syncthreads();
+        // dword f of the workgroup's range = cell f % CELLS of env f / CELLS; a lane walks its stores 1024 dwords apart
+        int le = (tid << 2) / CELLS, c = (tid << 2) - le * CELLS;
+        const int dle = (LMAZE_BLOCK << 2) / CELLS, dc = (LMAZE_BLOCK << 2) - dle * CELLS;
+        for (int q = tid; q < nq; q += LMAZE_BLOCK) {
+            int vals[4], l2 = le, c2 = c;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                int v = pat[c2];
+                v |= (ballflat[l2] == c2) ? LMAZE_OBS_BALL : 0;
+                if (V3) v |= (goalflat[l2] == c2) ? LMAZE_OBS_GOAL : 0;
+                vals[j] = v;
+                if (++c2 == CELLS) { c2 = 0; ++l2; }
+            }
+            reinterpret_cast<int4*>(obs)[q] = make_int4(vals[0], vals[1], vals[2], vals[3]);
+            le += dle; c += dc;
+            if (c >= CELLS) { c -= CELLS; ++le; }
+        }
+        const int f = (nq << 2) + tid;                                                // ragged tail: nb*G*G not a multiple of 4
+        if (f < R) {
+            const int l2 = f / CELLS, c2 = f - l2 * CELLS;
+            int v = pat[c2];
+            v |= (ballflat[l2] == c2) ? LMAZE_OBS_BALL : 0;
+            if (V3) v |= (goalflat[l2] == c2) ? LMAZE_OBS_GOAL : 0;
+            obs[f] = v;
+        }
+        __syncthreads();                                                              // ballflat / goalflat are rewritten by the next step
+    }
+    if (live && ro.T > 0) {
+        a.ball[e] = b;
+        if (V3 && autoreset) a.goal_rw[e] = g;
+        a.step_count[e] = sc;
+        a.reward[e] = r;
+        a.done[e] = dn ? 1 : 0;
+        if (hits && a.goal_count) a.goal_count[e] += hits;
+    }
+}
+
 // ------------------------------------------------------------------------------------
 // host launchers
 // ------------------------------------------------------------------------------------
@@ -1330,8 +1445,8 @@ hipError_t launch_step_u8(int variant, bool do_step, const StepArgs& a, hipStrea
     return launch_step_u8_epb<64>(variant, do_step, a, s);
 }
 
-// T steps: ONE launch where the batch is an on-die shared 8x8 one (see rollout_shared_wave8_kernel), else T launches of
-// the step kernel, step t with the action row t, epoch + t and, when given, the per-step reward / done rows copied out.
+// T steps: ONE launch where the batch is a shared-layout one whose planes stay on-die (8x8: rollout_shared_wave8_kernel,
+// any other grid: rollout_shared_kernel), else T launches of the step kernel, step t with the action row t, epoch + t and, when given, the per-step reward / done rows copied out.
 hipError_t launch_rollout(int variant, const StepArgs& a0, int layout_mode, const int32_t* actions, int32_t T, float* reward_t,
                           uint8_t* done_t, hipStream_t s) {
     if (T <= 0 || a0.n == 0) return hipSuccess;
@@ -1352,6 +1467,30 @@ hipError_t launch_rollout(int variant, const StepArgs& a0, int layout_mode, cons
             hipLaunchKernelGGL((rollout_shared_wave8_kernel<LMAZE_VARIANT_V3, 64>), dim3((unsigned)blocks), dim3(64 * wpb), 0, s, a0, ro);
         else
             hipLaunchKernelGGL((rollout_shared_wave8_kernel<LMAZE_VARIANT_V0, 64>), dim3((unsigned)blocks), dim3(64 * wpb), 0, s, a0, ro);
+        return hipGetLastError();
+    }
+    // any other shared-layout batch whose planes stay on-die (the step kernel's own threshold for streaming stores):
+    // one launch of rollout_shared_kernel, a workgroup per 16 / 32 / 64 envs so that small batches still fill the chip
+    const bool on_die = layout_mode == LMAZE_LAYOUT_SHARED && T > 1 &&
+                        (a0.obs == nullptr || (size_t)a0.n * a0.grid * a0.grid * 4 <= kNonTemporalObsBytes) && (a0.launch_hint & 0x100) == 0;
+    if (on_die) {
+        RolloutArgs ro{actions, reward_t, done_t, T};
+        StepArgs a = a0;
+        a.envs_per_block = a0.n >= 65536 ? 64 : (a0.n >= 16384 ? 32 : 16);
+        const int cells = a0.grid * a0.grid;
+        const size_t lds = (size_t)cells * 4 + 2 * (size_t)a.envs_per_block * 4 + (size_t)((cells + 15) & ~15) + (size_t)((cells * 2 + 15) & ~15);
+        const int64_t blocks = (a0.n + a.envs_per_block - 1) / a.envs_per_block;
+        if (!grid_ok(blocks)) return hipErrorInvalidConfiguration;
+        if (a0.info) {
+            char name[96];
+            snprintf(name, sizeof(name), "rollout_shared_kernel<v%d> T=%d", variant, T);
+            describe_launch(a0.info, name, a.envs_per_block, 0, 1, false, blocks, LMAZE_BLOCK, lds);
+            return hipSuccess;
+        }
+        if (variant == LMAZE_VARIANT_V3)
+            hipLaunchKernelGGL((rollout_shared_kernel<LMAZE_VARIANT_V3>), dim3((unsigned)blocks), dim3(LMAZE_BLOCK), lds, s, a, ro);
+        else
+            hipLaunchKernelGGL((rollout_shared_kernel<LMAZE_VARIANT_V0>), dim3((unsigned)blocks), dim3(LMAZE_BLOCK), lds, s, a, ro);
         return hipGetLastError();
     }
     for (int32_t t = 0; t < T; ++t) {

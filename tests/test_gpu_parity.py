@@ -640,11 +640,43 @@ def test_rollout_in_one_launch_equals_T_step_calls(variant, auto_reset, T):
             assert int(one.goal_count.sum().item()) == int(ref.goal_count.sum().item())
 
 
-def test_rollout_other_shapes_run_T_launches_inside_the_library():
-    """Every other shape: lmaze_rollout issues the T step launches itself -- the same results, trajectory rows included."""
-    N, T = 5000, 9
-    one = PKG.LmazeVecEnv(N, variant="v0", layout=PKG.layouts.open_room(11, (5, 5)), seed=2)
-    ref = PKG.LmazeVecEnv(N, variant="v0", layout=PKG.layouts.open_room(11, (5, 5)), seed=2)
+@pytest.mark.parametrize("variant,G,N,T", [("v0", 11, 5000, 9), ("v3", 11, 70000, 40), ("v0", 12, 1000, 130), ("v3", 18, 300, 25),
+                                           ("v0", 33, 100, 12), ("v3", 5, 17, 60), ("v0", 11, 65536, 16), ("v3", 64, 33, 7)])
+@pytest.mark.parametrize("auto_reset", [False, True])
+def test_rollout_of_any_on_die_shared_batch_is_one_launch(variant, G, N, T, auto_reset):
+    """Shared layouts of any grid size whose planes stay on-die: lmaze_rollout is ONE launch of rollout_shared_kernel (a
+    workgroup keeps its envs' state in registers across the T steps) -- state, planes, goal counts and every step's reward /
+    done row bit-identical to T calls of lmaze_step_* (fused reset: the same placements, epoch + t); even and odd G, ragged
+    batches, out-of-range action ids."""
+    lay = PKG.layouts.open_room(G, (G // 2, G // 2)) if G != 12 else PKG.layouts.V0_GRID_12
+    one = PKG.LmazeVecEnv(N, variant=variant, layout=lay, seed=2, env_base=5)
+    ref = PKG.LmazeVecEnv(N, variant=variant, layout=lay, seed=2, env_base=5)
+    gen = torch.Generator(device="cuda").manual_seed(G * 100 + T)
+    acts = torch.randint(-1, 6, (T, N), dtype=torch.int32, device="cuda", generator=gen)
+    obs, rew, done, rew_t, done_t = one.rollout(acts, auto_reset=auto_reset, trajectory=True)
+    for t in range(T):
+        o, r, d, _ = ref.step(acts[t], auto_reset=auto_reset)
+        assert (rew_t[t].view(torch.int32) == r.view(torch.int32)).all(), t
+        assert (done_t[t] == d).all(), t
+    h1, h2 = one.host_state(), ref.host_state()
+    for k in h1:
+        assert (np.ascontiguousarray(h1[k]).view(np.uint8) == np.ascontiguousarray(h2[k]).view(np.uint8)).all(), k
+    assert (one.obs == ref.obs).all() and one._epoch == ref._epoch
+    assert (one.goal_count == ref.goal_count).all()
+    # a second rollout continues where the first ended (done flags carried across calls)
+    one.rollout(acts[: min(T, 5)], auto_reset=auto_reset)
+    for t in range(min(T, 5)):
+        ref.step(acts[t], auto_reset=auto_reset)
+    assert (one.obs == ref.obs).all() and (one.ball_xy == ref.ball_xy).all() and (one.step_count == ref.step_count).all()
+
+
+def test_rollout_of_streaming_and_per_env_batches_runs_T_launches_inside_the_library():
+    """Per-env layouts (and batches too large to stay on-die, test_u8_observation_at_c3_size_and_refusals): lmaze_rollout
+    issues the T step launches itself -- the same results, trajectory rows included."""
+    N, T, G = 3000, 9, 11
+    lays = PKG.layouts.random_walled(N, G, torch.device("cuda"), seed=7)
+    one = PKG.LmazeVecEnv(N, variant="v0", per_env_layouts=lays, seed=2)
+    ref = PKG.LmazeVecEnv(N, variant="v0", per_env_layouts=lays, seed=2)
     acts = torch.randint(0, 4, (T, N), dtype=torch.int32, device="cuda")
     obs, rew, done, rew_t, done_t = one.rollout(acts, auto_reset=True, trajectory=True)
     for t in range(T):
