@@ -217,7 +217,7 @@ __global__ __launch_bounds__(LMAZE_BLOCK) void render_expanded_stream_kernel(con
             if (NT) {
                 typedef float f4 __attribute__((ext_vector_type(4)));
                 f4 t = {v[0], v[1], v[2], v[3]};
-                __builtin_nontemporal_store(t, reinterpret_cast<f4*>(dst) + q);
+                stream_store16(reinterpret_cast<f4*>(dst) + q, t);
             } else {
                 reinterpret_cast<float4*>(dst)[q] = make_float4(v[0], v[1], v[2], v[3]);
             }
@@ -367,7 +367,7 @@ __global__ __launch_bounds__(LMAZE_BLOCK) void render_planes_stream_kernel(const
             if (NT) {
                 typedef float f4 __attribute__((ext_vector_type(4)));
                 f4 t = {v[0], v[1], v[2], v[3]};
-                __builtin_nontemporal_store(t, reinterpret_cast<f4*>(dst) + q);
+                stream_store16(reinterpret_cast<f4*>(dst) + q, t);
             } else {
                 reinterpret_cast<float4*>(dst)[q] = make_float4(v[0], v[1], v[2], v[3]);
             }

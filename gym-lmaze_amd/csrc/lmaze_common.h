@@ -11,6 +11,20 @@
 
 namespace lmaze {
 
+// The streaming 16-byte store of every observation writer.  BITS picks the gfx950 cache-policy bits: 0 = the compiler's
+// non-temporal store (`nt`), 2 = `sc0 sc1 nt` (system-scope write-through + streaming).  tools/stbench.hip: the bare
+// 507-MB fill runs 72.1 us with `sc0 sc1 nt` / `sc1` against 75.6-76.2 with `nt` and 74.2-74.8 plain -- but of the kernels
+// only the per-env-layout step follows (1M x 32x32: 834-840 us against 884-888, three interleaved passes); the
+// shared-layout step, v1 and v2 lose 3-10 % and v5 20 % with it (profiles/r03/studies/stream_bits.txt), so it is a
+// per-kernel choice.  The asm form carries no memory clobber: observations are write-only inside a kernel.
+template <int BITS = 0, typename V4>
+__device__ __forceinline__ void stream_store16(V4* p, V4 t) {
+    static_assert(sizeof(V4) == 16, "one dwordx4");
+    if constexpr (BITS == 2) asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1 nt" ::"v"(p), "v"(t));
+    else __builtin_nontemporal_store(t, p);
+}
+
+
 // What a launcher decided, for lmaze_describe_step / lmaze_describe_foveal_step (include/lmaze.h): filled INSTEAD of
 // launching when the args carry a pointer to one, by the very code that launches otherwise.
 struct LaunchInfo {

@@ -950,7 +950,7 @@ __global__ __launch_bounds__(LMAZE_BLOCK) LMAZE_FOVEAL_ATTR void foveal_kernel(c
             typedef float v4f __attribute__((ext_vector_type(4)));
             v4f t = {v[0], v[1], v[2], v[3]};
             v4f* dst = reinterpret_cast<v4f*>(gbase) + (size_t)(k * 8 + w) * 256 + tid;
-            if (a.nt) __builtin_nontemporal_store(t, dst); else *dst = t;
+            if (a.nt) stream_store16(dst, t); else *dst = t;
         }
     }
     const int nq_run = (LMAZE_XP(a, 4) || (LMAZE_XP(a, 16) && !V4 && EPB == 128)) ? 0 : nq;
@@ -981,7 +981,7 @@ __global__ __launch_bounds__(LMAZE_BLOCK) LMAZE_FOVEAL_ATTR void foveal_kernel(c
         if (a.nt) {  // large batches: the observation cannot stay in the Infinity Cache, stream it (+6...12 %)
             typedef float v4f __attribute__((ext_vector_type(4)));
             v4f t = {v[0], v[1], v[2], v[3]};
-            __builtin_nontemporal_store(t, reinterpret_cast<v4f*>(obs) + q);
+            stream_store16(reinterpret_cast<v4f*>(obs) + q, t);
         } else {
             reinterpret_cast<float4*>(obs)[q] = make_float4(v[0], v[1], v[2], v[3]);
         }
@@ -1007,7 +1007,7 @@ __global__ __launch_bounds__(LMAZE_BLOCK) LMAZE_FOVEAL_ATTR void foveal_kernel(c
             if (a.nt) {   // streamed like the foveal observation (round 3: these 400 B per env were plain stores)
                 typedef float v4f __attribute__((ext_vector_type(4)));
                 v4f t = {v[0], v[1], v[2], v[3]};
-                __builtin_nontemporal_store(t, reinterpret_cast<v4f*>(loc) + q);
+                stream_store16(reinterpret_cast<v4f*>(loc) + q, t);
             } else {
                 reinterpret_cast<float4*>(loc)[q] = make_float4(v[0], v[1], v[2], v[3]);
             }
@@ -1156,7 +1156,7 @@ __global__ __launch_bounds__(LMAZE_BLOCK) void expand_planes_stream_kernel(const
             if (NT) {
                 typedef float f4 __attribute__((ext_vector_type(4)));
                 f4 t = {v[0], v[1], v[2], v[3]};
-                __builtin_nontemporal_store(t, reinterpret_cast<f4*>(dst) + q);
+                stream_store16(reinterpret_cast<f4*>(dst) + q, t);
             } else {
                 reinterpret_cast<float4*>(dst)[q] = make_float4(v[0], v[1], v[2], v[3]);
             }
