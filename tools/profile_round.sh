@@ -1,7 +1,10 @@
 #!/bin/bash
 # Re-records profiles/rNN on the GPU box:  bash tools/profile_round.sh 2   (run through gpurun; writes gpurun_out/prof_rNN/)
-# Every rocprofv3 pass profiles `python3 bench.py ...` with the launch policy FIXED (--launch-hint) to the one the
-# un-profiled bench line of the same box was measured with, so the --stats average is the timed policy's.
+# Every rocprofv3 pass profiles `python3 bench.py ...` with the launch policy FIXED (--launch-hint): the LIBRARY DEFAULT
+# (hint 0) unless PROFILE_TUNED=1 asks for the policy the un-profiled line's autotune() kept on this box.  A profiled
+# process makes one allocation and tries no placements, and a tuned policy can be placement-sensitive where the default is
+# not (profiles/README.md, final_c: (5, 2) on C3 75.6 us tuned, 92 us in the profiled process); compare the --stats
+# average with the line's roofline.frac_untuned_library.
 R=${1:-2}
 RR=$(printf "r%02d" $R)
 ROOT=${GRAFT_REPO_ROOT:-$PWD}
@@ -15,6 +18,7 @@ H=35
 if has c3; then
 $B > $OUT/bench_c3.json 2> $OUT/bench_c3.err || exit 1
 H=$(python3 -c "import json; print(json.load(open('$OUT/bench_c3.json'))['config']['launch_hint'])")
+[ -z "$PROFILE_TUNED" ] && H=0
 echo "c3 launch hint $H"
 $B --auto-reset --no-cpu-baseline > $OUT/bench_c3_autoreset.json 2>/dev/null
 # kernel trace + stats, the timed policy on every launch
@@ -22,7 +26,7 @@ rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_c3 -- $B --la
 fi
 for w in c2 c5 v1 v2 v4 v5; do has $w || continue; $B --workload $w > $OUT/bench_$w.json 2> $OUT/bench_$w.err; echo "$w rc=$?"; done
 # the launch policy each un-profiled line was tuned to on THIS box: fixed for every profiled pass below
-hint() { python3 -c "import json; print(json.load(open('$OUT/bench_$1.json'))['config']['launch_hint'])" 2>/dev/null || echo 0; }
+hint() { [ -z "$PROFILE_TUNED" ] && { echo 0; return; }; python3 -c "import json; print(json.load(open('$OUT/bench_$1.json'))['config']['launch_hint'])" 2>/dev/null || echo 0; }
 has c2 && $B --workload c2 --graph --no-cpu-baseline > $OUT/bench_c2_graph.json 2>/dev/null
 for w in v1 v2 v4 v5 c5 c2; do
   has $w || continue
