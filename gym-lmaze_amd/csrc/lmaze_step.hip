@@ -1114,6 +1114,119 @@ __global__ __launch_bounds__(LMAZE_BLOCK) void rollout_shared_kernel(const StepA
     }
 }
 
+// The same for per-env layouts: the workgroup's EPB layouts (EPB * G * G bytes) are copied to LDS once and serve the
+// collision check, the planes and -- a done env, fused reset -- the whole-wave placement on the env's own maze (wave_place,
+// the rule of the per-env step kernels) for all T steps.  EPB <= 64: every env's lane sits in wave 0, which places the
+// done envs one after the other.
+template <int VARIANT>
+__global__ __launch_bounds__(LMAZE_BLOCK) void rollout_perenv_kernel(const StepArgs a, const RolloutArgs ro) {
+    constexpr bool V3 = VARIANT == LMAZE_VARIANT_V3;
+    const int G = a.grid, CELLS = G * G, EPB = a.envs_per_block;
+    extern __shared__ int4 lds4[];
+    int* ballflat = reinterpret_cast<int*>(lds4);                             // [EPB] cell of the ball
+    int* goalflat = ballflat + EPB;                                           // [EPB]
+    uint8_t* lays = reinterpret_cast<uint8_t*>(goalflat + EPB);               // [EPB * CELLS]
+
+    const int tid = threadIdx.x;
+    const int64_t blockbase = (int64_t)blockIdx.x * EPB;
+    const int nb = (int)min((int64_t)EPB, a.n - blockbase);
+    const bool autoreset = a.auto_reset != 0, live = tid < nb;
+    const int64_t e = blockbase + tid;
+    int2 b = make_int2(1, 1), g = make_int2(-1, -1);
+    int sc = 0, was_done = 0, hits = 0, act_next = -1;
+    float r = 0.0f;
+    if (live) {
+        b = a.ball[e];
+        if (V3) g = a.goal[e];
+        sc = a.step_count[e];
+        if (!V3) r = a.reward[e];
+        if (autoreset) was_done = a.done[e];
+        act_next = ro.actions[e];
+    }
+    {   // EPB is a multiple of 4: the workgroup's layouts start on a dword and are whole dwords
+        const uint32_t* src = reinterpret_cast<const uint32_t*>(a.layout + (size_t)blockbase * CELLS);
+        uint32_t* dst = reinterpret_cast<uint32_t*>(lays);
+        const int nw = (nb * CELLS) >> 2;
+        for (int i = tid; i < nw; i += LMAZE_BLOCK) dst[i] = src[i];
+        for (int i = (nw << 2) + tid; i < nb * CELLS; i += LMAZE_BLOCK) lays[i] = a.layout[(size_t)blockbase * CELLS + i];
+    }
+    __syncthreads();
+
+    int32_t* obs = a.obs ? a.obs + (size_t)blockbase * CELLS : nullptr;
+    const int R = nb * CELLS, nq = R >> 2;
+    bool dn = false;
+    for (int t = 0; t < ro.T; ++t) {
+        if (tid < 64) {                                                               // wave 0, every lane: the ballots below
+            const int act = act_next;
+            if (live && t + 1 < ro.T) act_next = ro.actions[(size_t)(t + 1) * a.n + e];
+            float r_in = r;
+            // reference reset() of the done envs, one whole-wave placement each on the env's own layout
+            unsigned long long todo = __ballot(live && autoreset && was_done);
+            while (todo) {
+                const int j = __ffsll((long long)todo) - 1;
+                todo &= todo - 1ull;
+                int bc, gc;
+                wave_place<VARIANT>(lays + j * CELLS, G, CELLS, env_draw(a.seed, a.epoch + (uint64_t)t, a.env_base + blockbase + j), tid, bc, gc);
+                if (tid == j) {
+                    if (bc >= 0) b = make_int2(bc / G, bc % G);
+                    if (V3 && gc >= 0) g = make_int2(gc / G, gc % G);
+                    sc = 0;         // v0:110
+                    r_in = -0.0f;   // v0:109
+                }
+            }
+            if (live) {
+                int bx = clampi(b.x, 0, G - 1), by = clampi(b.y, 0, G - 1);
+                sc += 1;            // v0:151, v3:225
+                int ox, oy;
+                decode_action(act, ox, oy);
+                const int tx = clampi(bx + ox, 0, G - 1), ty = clampi(by + oy, 0, G - 1);
+                hits += transition_rule<VARIANT>(a, lays[tid * CELLS + tx * G + ty], ox, oy, tx, ty, sc, r_in, g.x, g.y, bx, by, r, dn) ? 1 : 0;
+                b = make_int2(bx, by);
+                was_done = dn ? 1 : 0;
+                if (ro.reward_t) ro.reward_t[(size_t)t * a.n + e] = r;
+                if (ro.done_t) ro.done_t[(size_t)t * a.n + e] = dn ? 1 : 0;
+                ballflat[tid] = b.x * G + b.y;
+                if (V3) goalflat[tid] = (g.x >= 0 && g.x < G && g.y >= 0 && g.y < G) ? g.x * G + g.y : -8;
+            }
+        }
+        if (obs == nullptr) continue;                                                 // uniform
+        __syncthreads();
+        int le = (tid << 2) / CELLS, c = (tid << 2) - le * CELLS;
+        const int dle = (LMAZE_BLOCK << 2) / CELLS, dc = (LMAZE_BLOCK << 2) - dle * CELLS;
+        for (int q = tid; q < nq; q += LMAZE_BLOCK) {
+            int vals[4], l2 = le, c2 = c;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                int v = cell_bits<VARIANT>(lays[l2 * CELLS + c2]);
+                v |= (ballflat[l2] == c2) ? LMAZE_OBS_BALL : 0;
+                if (V3) v |= (goalflat[l2] == c2) ? LMAZE_OBS_GOAL : 0;
+                vals[j] = v;
+                if (++c2 == CELLS) { c2 = 0; ++l2; }
+            }
+            reinterpret_cast<int4*>(obs)[q] = make_int4(vals[0], vals[1], vals[2], vals[3]);
+            le += dle; c += dc;
+            if (c >= CELLS) { c -= CELLS; ++le; }
+        }
+        const int f = (nq << 2) + tid;                                                // ragged tail
+        if (f < R) {
+            const int l2 = f / CELLS, c2 = f - l2 * CELLS;
+            int v = cell_bits<VARIANT>(lays[l2 * CELLS + c2]);
+            v |= (ballflat[l2] == c2) ? LMAZE_OBS_BALL : 0;
+            if (V3) v |= (goalflat[l2] == c2) ? LMAZE_OBS_GOAL : 0;
+            obs[f] = v;
+        }
+        __syncthreads();
+    }
+    if (live && ro.T > 0) {
+        a.ball[e] = b;
+        if (V3 && autoreset) a.goal_rw[e] = g;
+        a.step_count[e] = sc;
+        a.reward[e] = r;
+        a.done[e] = dn ? 1 : 0;
+        if (hits && a.goal_count) a.goal_count[e] += hits;
+    }
+}
+
 // ------------------------------------------------------------------------------------
 // host launchers
 // ------------------------------------------------------------------------------------
@@ -1445,8 +1558,8 @@ hipError_t launch_step_u8(int variant, bool do_step, const StepArgs& a, hipStrea
     return launch_step_u8_epb<64>(variant, do_step, a, s);
 }
 
-// T steps: ONE launch where the batch is a shared-layout one whose planes stay on-die (8x8: rollout_shared_wave8_kernel,
-// any other grid: rollout_shared_kernel), else T launches of the step kernel, step t with the action row t, epoch + t and, when given, the per-step reward / done rows copied out.
+// T steps: ONE launch where the planes stay on-die (shared 8x8: rollout_shared_wave8_kernel, any other shared grid:
+// rollout_shared_kernel, per-env layouts: rollout_perenv_kernel), else T launches of the step kernel, step t with the action row t, epoch + t and, when given, the per-step reward / done rows copied out.
 hipError_t launch_rollout(int variant, const StepArgs& a0, int layout_mode, const int32_t* actions, int32_t T, float* reward_t,
                           uint8_t* done_t, hipStream_t s) {
     if (T <= 0 || a0.n == 0) return hipSuccess;
@@ -1491,6 +1604,34 @@ hipError_t launch_rollout(int variant, const StepArgs& a0, int layout_mode, cons
             hipLaunchKernelGGL((rollout_shared_kernel<LMAZE_VARIANT_V3>), dim3((unsigned)blocks), dim3(LMAZE_BLOCK), lds, s, a, ro);
         else
             hipLaunchKernelGGL((rollout_shared_kernel<LMAZE_VARIANT_V0>), dim3((unsigned)blocks), dim3(LMAZE_BLOCK), lds, s, a, ro);
+        return hipGetLastError();
+    }
+    // (grids the register-tiled one-wave-per-env step kernel serves -- G*G a multiple of 256 -- only while the launch itself
+    // is the cost: 8 192 x 32x32, 33 MB of planes, 10.2 us per step as launches and 10.5 as one launch; 4 096 x 12x12 7.4 -> 2.5)
+    const size_t plane_bytes = (size_t)a0.n * a0.grid * a0.grid * 4;
+    const bool wave_tiled = (a0.grid * a0.grid) % 256 == 0;
+    const bool on_die_perenv = layout_mode == LMAZE_LAYOUT_PER_ENV && T > 1 && (a0.launch_hint & 0x100) == 0 &&
+                               (a0.obs == nullptr || plane_bytes <= (wave_tiled ? (size_t)12 << 20 : kNonTemporalObsBytes));
+    if (on_die_perenv) {
+        RolloutArgs ro{actions, reward_t, done_t, T};
+        StepArgs a = a0;
+        const int cells = a0.grid * a0.grid;
+        int epb = a0.n >= 65536 ? 64 : (a0.n >= 16384 ? 32 : 16);
+        while (epb > 4 && (size_t)epb * cells > (size_t)32 << 10) epb >>= 1;         // at most 32 KiB of layouts per workgroup
+        a.envs_per_block = epb;
+        const size_t lds = 2 * (size_t)epb * 4 + (((size_t)epb * cells + 15) & ~(size_t)15);
+        const int64_t blocks = (a0.n + epb - 1) / epb;
+        if (!grid_ok(blocks)) return hipErrorInvalidConfiguration;
+        if (a0.info) {
+            char name[96];
+            snprintf(name, sizeof(name), "rollout_perenv_kernel<v%d> T=%d", variant, T);
+            describe_launch(a0.info, name, epb, 0, 1, false, blocks, LMAZE_BLOCK, lds);
+            return hipSuccess;
+        }
+        if (variant == LMAZE_VARIANT_V3)
+            hipLaunchKernelGGL((rollout_perenv_kernel<LMAZE_VARIANT_V3>), dim3((unsigned)blocks), dim3(LMAZE_BLOCK), lds, s, a, ro);
+        else
+            hipLaunchKernelGGL((rollout_perenv_kernel<LMAZE_VARIANT_V0>), dim3((unsigned)blocks), dim3(LMAZE_BLOCK), lds, s, a, ro);
         return hipGetLastError();
     }
     for (int32_t t = 0; t < T; ++t) {

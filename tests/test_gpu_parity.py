@@ -670,19 +670,31 @@ def test_rollout_of_any_on_die_shared_batch_is_one_launch(variant, G, N, T, auto
     assert (one.obs == ref.obs).all() and (one.ball_xy == ref.ball_xy).all() and (one.step_count == ref.step_count).all()
 
 
-def test_rollout_of_streaming_and_per_env_batches_runs_T_launches_inside_the_library():
-    """Per-env layouts (and batches too large to stay on-die, test_u8_observation_at_c3_size_and_refusals): lmaze_rollout
-    issues the T step launches itself -- the same results, trajectory rows included."""
-    N, T, G = 3000, 9, 11
-    lays = PKG.layouts.random_walled(N, G, torch.device("cuda"), seed=7)
-    one = PKG.LmazeVecEnv(N, variant="v0", per_env_layouts=lays, seed=2)
-    ref = PKG.LmazeVecEnv(N, variant="v0", per_env_layouts=lays, seed=2)
-    acts = torch.randint(0, 4, (T, N), dtype=torch.int32, device="cuda")
-    obs, rew, done, rew_t, done_t = one.rollout(acts, auto_reset=True, trajectory=True)
+@pytest.mark.parametrize("variant,G,N,T", [("v0", 11, 3000, 9), ("v3", 11, 20000, 30), ("v0", 32, 1000, 12), ("v3", 13, 70, 50),
+                                           ("v0", 32, 70001, 6), ("v3", 64, 21, 5), ("v0", 5, 130, 40)])
+@pytest.mark.parametrize("auto_reset", [False, True])
+def test_rollout_of_on_die_per_env_batches_is_one_launch(variant, G, N, T, auto_reset):
+    """Per-env layouts whose planes stay on-die: lmaze_rollout is ONE launch of rollout_perenv_kernel (the workgroup's
+    layouts in LDS for all T steps; a done env is re-placed by a whole wave on its own maze, the per-env step kernels' rule)
+    -- bit-identical to T calls of lmaze_step_* incl. every step's reward / done row.  Batches too large to stay on-die run T
+    launches inside the call (test_u8_observation_at_c3_size_and_refusals)."""
+    lays = PKG.layouts.random_walled(N, G, torch.device("cuda"), seed=7 + G)
+    one = PKG.LmazeVecEnv(N, variant=variant, per_env_layouts=lays, seed=2, env_base=11)
+    ref = PKG.LmazeVecEnv(N, variant=variant, per_env_layouts=lays, seed=2, env_base=11)
+    gen = torch.Generator(device="cuda").manual_seed(G * 100 + T)
+    acts = torch.randint(-1, 6, (T, N), dtype=torch.int32, device="cuda", generator=gen)
+    obs, rew, done, rew_t, done_t = one.rollout(acts, auto_reset=auto_reset, trajectory=True)
     for t in range(T):
-        o, r, d, _ = ref.step(acts[t], auto_reset=True)
-        assert (rew_t[t].view(torch.int32) == r.view(torch.int32)).all() and (done_t[t] == d).all()
-    assert (one.obs == ref.obs).all() and (one.ball_xy == ref.ball_xy).all() and one._epoch == ref._epoch
+        o, r, d, _ = ref.step(acts[t], auto_reset=auto_reset)
+        assert (rew_t[t].view(torch.int32) == r.view(torch.int32)).all() and (done_t[t] == d).all(), t
+    h1, h2 = one.host_state(), ref.host_state()
+    for k in h1:
+        assert (np.ascontiguousarray(h1[k]).view(np.uint8) == np.ascontiguousarray(h2[k]).view(np.uint8)).all(), k
+    assert (one.obs == ref.obs).all() and one._epoch == ref._epoch and (one.goal_count == ref.goal_count).all()
+    one.rollout(acts[: min(T, 4)], auto_reset=auto_reset)
+    for t in range(min(T, 4)):
+        ref.step(acts[t], auto_reset=auto_reset)
+    assert (one.obs == ref.obs).all() and (one.ball_xy == ref.ball_xy).all() and (one.step_count == ref.step_count).all()
 
 
 # ---------------------------------------------------------------- narrow observation (uint8 planes)
