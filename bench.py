@@ -606,8 +606,9 @@ def main():
             kernel = "lmaze::" + abi.describe_step(env.params, N, auto_reset=bool(args.auto_reset),
                                                    with_obs="u8" if args.obs_dtype == "u8" else True)
             if args.one_launch:
-                kernel += (" -- timed as ONE lmaze_rollout call of %d steps (rollout_shared_wave8_kernel at 8x8, rollout_shared_kernel "
-                           "at other grids, where the planes stay on-die)" % args.steps)
+                kernel += (" -- timed as ONE lmaze_rollout call of %d steps (shared layouts: rollout_shared_wave8_kernel for on-die "
+                           "8x8 batches, rollout_shared_kernel otherwise; per-env layouts: rollout_perenv_kernel while the planes "
+                           "stay on-die, else that many launches inside the call)" % args.steps)
             perenv_kernel = None
             if args.per_env_layouts:
                 # BASELINE config 5 names an LDS-tiled maze per workgroup; at G*G a multiple of 256 the register-tiled

@@ -1558,8 +1558,8 @@ hipError_t launch_step_u8(int variant, bool do_step, const StepArgs& a, hipStrea
     return launch_step_u8_epb<64>(variant, do_step, a, s);
 }
 
-// T steps: ONE launch where the planes stay on-die (shared 8x8: rollout_shared_wave8_kernel, any other shared grid:
-// rollout_shared_kernel, per-env layouts: rollout_perenv_kernel), else T launches of the step kernel, step t with the action row t, epoch + t and, when given, the per-step reward / done rows copied out.
+// T steps: ONE launch for shared layouts (on-die 8x8: rollout_shared_wave8_kernel, everything else: rollout_shared_kernel)
+// and for per-env layouts whose planes stay on-die (rollout_perenv_kernel), else T launches of the step kernel, step t with the action row t, epoch + t and, when given, the per-step reward / done rows copied out.
 hipError_t launch_rollout(int variant, const StepArgs& a0, int layout_mode, const int32_t* actions, int32_t T, float* reward_t,
                           uint8_t* done_t, hipStream_t s) {
     if (T <= 0 || a0.n == 0) return hipSuccess;
@@ -1582,10 +1582,11 @@ hipError_t launch_rollout(int variant, const StepArgs& a0, int layout_mode, cons
             hipLaunchKernelGGL((rollout_shared_wave8_kernel<LMAZE_VARIANT_V0, 64>), dim3((unsigned)blocks), dim3(64 * wpb), 0, s, a0, ro);
         return hipGetLastError();
     }
-    // any other shared-layout batch whose planes stay on-die (the step kernel's own threshold for streaming stores):
-    // one launch of rollout_shared_kernel, a workgroup per 16 / 32 / 64 envs so that small batches still fill the chip
-    const bool on_die = layout_mode == LMAZE_LAYOUT_SHARED && T > 1 &&
-                        (a0.obs == nullptr || (size_t)a0.n * a0.grid * a0.grid * 4 <= kNonTemporalObsBytes) && (a0.launch_hint & 0x100) == 0;
+    // any other shared-layout batch: one launch of rollout_shared_kernel, a workgroup per 16 / 32 / 64 envs so that small
+    // batches still fill the chip.  Streaming sizes too: the planes of every step still go out to HBM, but the state stays
+    // in registers and there is no per-step set-up -- 1M x 11x11 75.4 us per step (fused reset 75.6) against 86.4 (92.5) as T
+    // launches from inside this call, 4M envs 297.8 against 329.7 (profiles/r03/rollout_streaming.txt)
+    const bool on_die = layout_mode == LMAZE_LAYOUT_SHARED && T > 1 && (a0.launch_hint & 0x100) == 0;
     if (on_die) {
         RolloutArgs ro{actions, reward_t, done_t, T};
         StepArgs a = a0;

@@ -697,6 +697,25 @@ def test_rollout_of_on_die_per_env_batches_is_one_launch(variant, G, N, T, auto_
     assert (one.obs == ref.obs).all() and (one.ball_xy == ref.ball_xy).all() and (one.step_count == ref.step_count).all()
 
 
+@pytest.mark.parametrize("variant,G,N", [("v0", 11, 1 << 20), ("v3", 18, 300001)])
+def test_rollout_of_a_streaming_shared_batch_is_one_launch_too(variant, G, N):
+    """Batches far beyond the caches (BASELINE's 1M x 11x11: 507 MB of planes): still one launch of rollout_shared_kernel,
+    still bit-identical to T step calls with fused resets, trajectory rows included."""
+    lay = PKG.layouts.open_room(G, (G // 2, G // 2))
+    one = PKG.LmazeVecEnv(N, variant=variant, layout=lay, seed=4, env_base=1 << 33)
+    ref = PKG.LmazeVecEnv(N, variant=variant, layout=lay, seed=4, env_base=1 << 33)
+    T = 6
+    acts = torch.randint(-1, 5, (T, N), dtype=torch.int32, device="cuda")
+    for env in (one, ref):                      # some envs already done when the rollout starts
+        env.step_count.fill_(env.params.step_limit - 2)
+    obs, rew, done, rew_t, done_t = one.rollout(acts, auto_reset=True, trajectory=True)
+    for t in range(T):
+        o, r, d, _ = ref.step(acts[t], auto_reset=True)
+        assert (rew_t[t].view(torch.int32) == r.view(torch.int32)).all() and (done_t[t] == d).all(), t
+    assert (one.obs == ref.obs).all() and (one.ball_xy == ref.ball_xy).all() and (one.step_count == ref.step_count).all()
+    assert one._epoch == ref._epoch and int(done.sum().item()) == int(ref.done.sum().item())
+
+
 # ---------------------------------------------------------------- narrow observation (uint8 planes)
 @pytest.mark.parametrize("variant,G,N", [("v0", 11, 5000), ("v0", 11, 64), ("v3", 11, 777), ("v0", 8, 4096), ("v0", 12, 1025),
                                          ("v3", 18, 300), ("v0", 5, 1000), ("v0", 4, 33), ("v0", 33, 130), ("v3", 64, 17)])
