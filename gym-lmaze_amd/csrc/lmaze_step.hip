@@ -1558,8 +1558,8 @@ hipError_t launch_step_u8(int variant, bool do_step, const StepArgs& a, hipStrea
     return launch_step_u8_epb<64>(variant, do_step, a, s);
 }
 
-// T steps: ONE launch for shared layouts (on-die 8x8: rollout_shared_wave8_kernel, everything else: rollout_shared_kernel)
-// and for per-env layouts whose planes stay on-die (rollout_perenv_kernel), else T launches of the step kernel, step t with the action row t, epoch + t and, when given, the per-step reward / done rows copied out.
+// T steps: ONE launch (shared layouts: rollout_shared_wave8_kernel for on-die 8x8, rollout_shared_kernel otherwise; per-env
+// layouts: rollout_perenv_kernel); T launches of the step kernel only for T = 1 or when launch_hint bit 8 forces streaming stores, step t with the action row t, epoch + t and, when given, the per-step reward / done rows copied out.
 hipError_t launch_rollout(int variant, const StepArgs& a0, int layout_mode, const int32_t* actions, int32_t T, float* reward_t,
                           uint8_t* done_t, hipStream_t s) {
     if (T <= 0 || a0.n == 0) return hipSuccess;
@@ -1607,12 +1607,11 @@ hipError_t launch_rollout(int variant, const StepArgs& a0, int layout_mode, cons
             hipLaunchKernelGGL((rollout_shared_kernel<LMAZE_VARIANT_V0>), dim3((unsigned)blocks), dim3(LMAZE_BLOCK), lds, s, a, ro);
         return hipGetLastError();
     }
-    // (grids the register-tiled one-wave-per-env step kernel serves -- G*G a multiple of 256 -- only while the launch itself
-    // is the cost: 8 192 x 32x32, 33 MB of planes, 10.2 us per step as launches and 10.5 as one launch; 4 096 x 12x12 7.4 -> 2.5)
-    const size_t plane_bytes = (size_t)a0.n * a0.grid * a0.grid * 4;
-    const bool wave_tiled = (a0.grid * a0.grid) % 256 == 0;
-    const bool on_die_perenv = layout_mode == LMAZE_LAYOUT_PER_ENV && T > 1 && (a0.launch_hint & 0x100) == 0 &&
-                               (a0.obs == nullptr || plane_bytes <= (wave_tiled ? (size_t)12 << 20 : kNonTemporalObsBytes));
+    // per-env layouts, any size: the layouts are read ONCE per rollout instead of once per step (1M x 32x32: 838 -> 722 us per
+    // step, 1M x 11x11 103 -> 100.5, with the fused reset 114 -> 105.7, 512K x 18x18 142 -> 114; only 8 192 x 32x32, where the
+    // register-tiled step kernel is neither launch- nor layout-bound, is 3 % slower: 10.2 -> 10.5;
+    // profiles/r03/rollout_streaming_perenv.txt, rollout_sizes_perenv.txt)
+    const bool on_die_perenv = layout_mode == LMAZE_LAYOUT_PER_ENV && T > 1 && (a0.launch_hint & 0x100) == 0;
     if (on_die_perenv) {
         RolloutArgs ro{actions, reward_t, done_t, T};
         StepArgs a = a0;

@@ -486,8 +486,8 @@ class LmazeVecEnv(object):
         sync (capture_rollout() records it into a hipGraph for launch-bound batch sizes).
         device_epoch: keep the reset epoch on the device (what capture_rollout uses; bit-identical to the
         host-counted epochs when begin_replay(T) precedes it).  Returns the final (obs, reward, done); trajectory=True adds
-        every step's reward float32[T,N] and done bool[T,N].  Batches whose planes stay on-die (BASELINE's 65 536 x 8x8, any
-        other grid and per-env layouts up to 192 MB of planes) run the whole rollout as ONE launch (include/lmaze.h
+        every step's reward float32[T,N] and done bool[T,N].  The whole rollout is ONE launch (shared and per-env
+        layouts, any batch size; the envs' state stays in registers across the T steps) (include/lmaze.h
         lmaze_rollout)."""
         if not (isinstance(actions, torch.Tensor) and actions.dtype == torch.int32 and actions.dim() == 2
                 and actions.shape[1] == self.num_envs and actions.device == self.device and actions.is_contiguous()):
@@ -495,8 +495,8 @@ class LmazeVecEnv(object):
         base, stride = actions.data_ptr(), self.num_envs * 4
         T, N = int(actions.shape[0]), self.num_envs
         if not device_epoch and self._tuner is None and not self._u8:
-            # lmaze_rollout: ONE launch for on-die batches (the envs' state stays in registers across the T
-            # steps), T launches from inside the library otherwise; bit-identical to T step() calls either way
+            # lmaze_rollout: ONE launch (the envs' state stays in registers across the T steps); bit-identical to T
+            # step() calls
             rew_t = torch.empty((T, N), dtype=torch.float32, device=self.device) if trajectory else None
             done_t = torch.empty((T, N), dtype=torch.uint8, device=self.device) if trajectory else None
             with self._guard():

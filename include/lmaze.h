@@ -226,13 +226,12 @@ int lmaze_observe_u8(const LmazeParams* params, const uint8_t* layout, const int
  * lmaze_step_v0 / _v3 -- with auto_reset != 0 of the *_autoreset forms, step t drawing with epoch + t -- with
  * bit-identical state and planes at the end (params->variant selects the rules; goal_xy for v3 only, goal_count for v0
  * only, both nullable as in the step calls).  reward_t float[T,N] / done_t uint8[T,N] (nullable) receive every step's
- * reward and done row.  Shared layouts of any grid and batch size, and per-env layouts while the planes stay on the die
- * (up to 192 MiB, e.g. 65 536 x 11x11), run the whole rollout as ONE launch: the lane that owns an env keeps its state in
- * registers across the T steps (on-die 8x8: a wave per 64 envs; otherwise a workgroup per 4-64 envs with the layout(s) in
- * LDS), the planes are rewritten every step as T launches would, the per-env state goes back once at the end (65 536 x 8x8:
- * a step costs 6 us as a launch of its own, a third of it launch gap, 2.3-2.5 us here; lmaze_describe_step names the step
- * kernel, this call its rollout form).  Larger per-env batches run T launches of the step kernel from inside this call.
- * The caller advances its epoch by T.
+ * reward and done row.  The whole rollout is ONE launch: the lane that owns an env keeps its state in registers across the
+ * T steps (on-die shared 8x8: a wave per 64 envs; otherwise a workgroup per 4-64 envs with the layout -- or its envs' own
+ * layouts -- in LDS, read once per rollout), the planes are rewritten every step as T launches would, the per-env state
+ * goes back once at the end (65 536 x 8x8: a step costs 6 us as a launch of its own, a third of it launch gap, 2.3-2.5 us
+ * here; 1M x 32x32 per-env layouts 838 -> 722 us per step; lmaze_describe_step names the step kernel, this call its
+ * rollout form).  The caller advances its epoch by T.
  */
 int lmaze_rollout(const LmazeParams* params, const uint8_t* layout, const int32_t* actions, int32_t T, int32_t* ball_xy,
                   int32_t* goal_xy, int32_t* step_count, float* reward, uint8_t* done, int32_t* goal_count, int32_t* obs,

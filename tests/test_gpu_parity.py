@@ -673,11 +673,10 @@ def test_rollout_of_any_on_die_shared_batch_is_one_launch(variant, G, N, T, auto
 @pytest.mark.parametrize("variant,G,N,T", [("v0", 11, 3000, 9), ("v3", 11, 20000, 30), ("v0", 32, 1000, 12), ("v3", 13, 70, 50),
                                            ("v0", 32, 70001, 6), ("v3", 64, 21, 5), ("v0", 5, 130, 40)])
 @pytest.mark.parametrize("auto_reset", [False, True])
-def test_rollout_of_on_die_per_env_batches_is_one_launch(variant, G, N, T, auto_reset):
-    """Per-env layouts whose planes stay on-die: lmaze_rollout is ONE launch of rollout_perenv_kernel (the workgroup's
-    layouts in LDS for all T steps; a done env is re-placed by a whole wave on its own maze, the per-env step kernels' rule)
-    -- bit-identical to T calls of lmaze_step_* incl. every step's reward / done row.  Batches too large to stay on-die run T
-    launches inside the call (test_u8_observation_at_c3_size_and_refusals)."""
+def test_rollout_of_per_env_batches_is_one_launch(variant, G, N, T, auto_reset):
+    """Per-env layouts, on-die and streaming sizes (70 001 x 32x32: 287 MB of planes): lmaze_rollout is ONE launch of
+    rollout_perenv_kernel (the workgroup's layouts in LDS for all T steps; a done env is re-placed by a whole wave on its own
+    maze, the per-env step kernels' rule) -- bit-identical to T calls of lmaze_step_* incl. every step's reward / done row."""
     lays = PKG.layouts.random_walled(N, G, torch.device("cuda"), seed=7 + G)
     one = PKG.LmazeVecEnv(N, variant=variant, per_env_layouts=lays, seed=2, env_base=11)
     ref = PKG.LmazeVecEnv(N, variant=variant, per_env_layouts=lays, seed=2, env_base=11)
