@@ -1591,6 +1591,18 @@ hipError_t launch_rollout(int variant, const StepArgs& a0, int layout_mode, cons
         RolloutArgs ro{actions, reward_t, done_t, T};
         StepArgs a = a0;
         a.envs_per_block = a0.n >= 65536 ? 64 : (a0.n >= 16384 ? 32 : 16);
+        // Batches whose planes do not fit the caches: few enough envs per workgroup that what the resident workgroups of an XCD
+        // rewrite step after step (8 per CU x 32 CUs x envs x 4 G^2 bytes) stays inside its 4-MiB L2 -- then most of the
+        // intermediate planes never travel to DRAM.  1M x 11x11: 64 envs 77.7 us per step, 32: 78.6, 16: 51.0, 8: 64.2, 4: 109;
+        // 512K x 18x18: 64: 89.2, 16: 98.4, 8: 74.2, 4: 76.2; 256K x 32x32 (no size fits): 146 / 140 / 133.7 / 141.6
+        // (profiles/r03/rollout_envs_per_workgroup.txt).  launch_hint bits 12-14 = k > 0 ask for 4 << (k - 1) envs.
+        // (Only beyond the Infinity Cache: 262 144 x 11x11, 127 MB of planes, runs 9.9 us per step at 64 envs and 12.9 at 16.)
+        if ((size_t)a0.n * a0.grid * a0.grid * 4 > kNonTemporalObsBytes) {
+            int fit = 64;
+            while (fit > 8 && (size_t)fit * a0.grid * a0.grid * 4 > 12288) fit >>= 1;
+            if (fit < a.envs_per_block) a.envs_per_block = fit;
+        }
+        if ((a0.launch_hint >> 12) & 7) a.envs_per_block = 4 << (((a0.launch_hint >> 12) & 7) - 1);
         const int cells = a0.grid * a0.grid;
         const size_t lds = (size_t)cells * 4 + 2 * (size_t)a.envs_per_block * 4 + (size_t)((cells + 15) & ~15) + (size_t)((cells * 2 + 15) & ~15);
         const int64_t blocks = (a0.n + a.envs_per_block - 1) / a.envs_per_block;

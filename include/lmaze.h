@@ -231,7 +231,9 @@ int lmaze_observe_u8(const LmazeParams* params, const uint8_t* layout, const int
  * layouts -- in LDS, read once per rollout), the planes are rewritten every step as T launches would, the per-env state
  * goes back once at the end (65 536 x 8x8: a step costs 6 us as a launch of its own, a third of it launch gap, 2.3-2.5 us
  * here; 1M x 32x32 per-env layouts 838 -> 722 us per step; lmaze_describe_step names the step kernel, this call its
- * rollout form).  The caller advances its epoch by T.
+ * rollout form; params->launch_hint bits 12-14 = k > 0: 4 << (k - 1) envs per workgroup of the shared-layout form
+ * instead of the size the library picks -- for batches beyond the L2s the largest that keeps the resident workgroups'
+ * planes inside them).  The caller advances its epoch by T.
  */
 int lmaze_rollout(const LmazeParams* params, const uint8_t* layout, const int32_t* actions, int32_t T, int32_t* ball_xy,
                   int32_t* goal_xy, int32_t* step_count, float* reward, uint8_t* done, int32_t* goal_count, int32_t* obs,
