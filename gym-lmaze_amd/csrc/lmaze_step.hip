@@ -1630,6 +1630,10 @@ hipError_t launch_rollout(int variant, const StepArgs& a0, int layout_mode, cons
         const int cells = a0.grid * a0.grid;
         int epb = a0.n >= 65536 ? 64 : (a0.n >= 16384 ? 32 : 16);
         while (epb > 4 && (size_t)epb * cells > (size_t)32 << 10) epb >>= 1;         // at most 32 KiB of layouts per workgroup
+        if ((size_t)a0.n * cells * 4 > kNonTemporalObsBytes)                         // beyond the caches: planes that fit the L2s, as above
+            while (epb > 8 && (size_t)epb * cells * 4 > 12288) epb >>= 1;
+        if ((a0.launch_hint >> 12) & 7) epb = 4 << (((a0.launch_hint >> 12) & 7) - 1);
+        if (epb > 64) epb = 64;                                                      // every env's lane sits in wave 0
         a.envs_per_block = epb;
         const size_t lds = 2 * (size_t)epb * 4 + (((size_t)epb * cells + 15) & ~(size_t)15);
         const int64_t blocks = (a0.n + epb - 1) / epb;
